@@ -1,0 +1,152 @@
+/* muscato_hip.h -- C ABI of libmuscato_hip.so: muscato's seed-and-extend hot path
+ * (muscato_screen -> muscato_confirm [-> per-read best+MMTol]) on AMD MI355X (gfx950).
+ *
+ * The reference (kshedden/muscato, pure Go) has no in-process plugin/FFI interface for
+ * this path: its boundary is two executables joined by snappy text files in TempDir,
+ *     exec.Command("muscato_screen",  config.json)        cmd/muscato/main.go:306-316
+ *     GNU sort of bmatch_k -> smatch_k                    cmd/muscato/main.go:318-385
+ *     exec.Command("muscato_confirm", config.json, k)     cmd/muscato/main.go:387-420
+ * with inputs  reads_sorted.txt.sz (unique reads), GeneFileName (one target per line,
+ * gene number = line index) and outputs rmatch_k.txt.sz, lines
+ * "read \t targetsub \t pos \t nmiss \t %011d"   (cmd/muscato_confirm/main.go:221-230).
+ * This header is the boundary a cgo (or any FFI) host binds instead of spawning those
+ * processes; INTEGRATION.md shows the cgo stub.  Each entry point names the reference
+ * code it replaces.
+ *
+ * Conventions
+ *   - plain C types only; no HIP / torch types cross the boundary.
+ *   - every function returning int returns 0 on success, non-zero on error; the text of
+ *     the last error of a context is musc_last_error(ctx).  Nothing aborts or throws
+ *     across the boundary (the reference convention is exit status != 0,
+ *     cmd/muscato/main.go:313-315, 411-415 -- the CLI maps errors to that).
+ *   - ownership: inputs are borrowed for the duration of the call; outputs returned
+ *     through musc_hit** are owned by the library until musc_free_hits().
+ *   - threading: one musc_ctx per GPU; calls on one ctx must be serialised by the caller;
+ *     different ctxs may be driven from different host threads (a Go caller must
+ *     runtime.LockOSThread() around a call sequence: HIP's current device is per thread).
+ *   - there is NO CPU fallback: if no gfx950 device is usable musc_init fails.
+ */
+#ifndef MUSCATO_HIP_H
+#define MUSCATO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUSC_ABI_VERSION 1
+#define MUSC_MAX_WINDOWS 16
+
+typedef struct musc_ctx musc_ctx;
+
+/* One accepted placement: read `read_idx` (index into the loaded unique reads) matches
+ * target `gene_idx` (line index of the gene file) at target offset `pos` with `nmiss`
+ * mismatches.  Equivalent to one rmatch_k / matches.txt line
+ * (cmd/muscato_confirm/main.go:221-230). */
+typedef struct {
+  uint32_t read_idx;
+  uint32_t gene_idx;
+  uint32_t pos;
+  uint32_t nmiss;
+} musc_hit;
+
+/* The part of utils.Config (utils/config.go:10-101) the hot path reads. */
+typedef struct {
+  int32_t n_windows;                 /* len(Config.Windows), 1..MUSC_MAX_WINDOWS       */
+  int32_t windows[MUSC_MAX_WINDOWS]; /* Config.Windows: start of each window in a read */
+  int32_t window_width;              /* Config.WindowWidth                             */
+  double pmatch;                     /* Config.PMatch; nmiss = int((1-PMatch)*len)     */
+  int32_t min_dinuc;                 /* Config.MinDinuc (utils/entropy.go:5-40 gate)   */
+  int32_t max_read_length;           /* Config.MaxReadLength                           */
+  int32_t max_matches;               /* Config.MaxMatches (per window-key block)       */
+  int32_t match_mode;                /* 0 = "best", 1 = "first" (Config.MatchMode)     */
+  int32_t mmtol;                     /* Config.MMTol                                   */
+  /* 0: return every accepted tuple = set-union of rmatch_0..W-1 (output of muscato_confirm
+   *    after combine_filter | sort -u, cmd/muscato/main.go:441-463);
+   * 1: additionally keep, per read, only nmiss <= best+MMTol = matches.txt
+   *    (cmd/muscato_combine_windows/main.go:36-60). */
+  int32_t apply_mmtol;
+  int32_t reserved[5];
+} musc_params;
+
+/* Counters and device timings of the last musc_match* call on a context. */
+typedef struct {
+  uint64_t n_reads;         /* unique reads processed                                  */
+  uint64_t n_read_windows;  /* (read, window) seeds that passed the length+entropy gate */
+  uint64_t n_pairs;         /* candidate (read, target position) pairs confirmed        */
+  uint64_t n_accepted;      /* pairs with nmiss <= budget, after the union over windows */
+  uint64_t n_hits;          /* tuples returned                                          */
+  uint64_t n_overflow_blocks; /* (window,key) blocks that may exceed MaxMatches (0 = exact) */
+  uint64_t confirm_bytes;   /* algorithmic bytes of the confirm launches (63 B/pair at 100 bp) */
+  uint32_t confirm_launches;
+  uint32_t n_batches;
+  float ms_seed;            /* HIP-event time of each kernel family, summed over batches */
+  float ms_scan;
+  float ms_expand;
+  float ms_confirm;
+  float ms_select;
+  float ms_total;           /* first launch to last completion on the context's stream  */
+  float ms_index_build;     /* last musc_db_build_index                                 */
+  float ms_reserved;
+} musc_stats;
+
+int musc_abi_version(void);
+
+/* Create / destroy a context bound to HIP device `device_ordinal` (one per GPU). */
+int musc_init(int device_ordinal, musc_ctx** out);
+void musc_destroy(musc_ctx* ctx);
+const char* musc_last_error(musc_ctx* ctx); /* ctx may be NULL: error of a failed musc_init */
+
+/* ---- target database: replaces muscato_screen's scan of GeneFileName
+ * (cmd/muscato_screen/main.go:408-452; gene number = sequence index). --------------------
+ *
+ * ASCII form: `seqs` holds nseq sequences back to back, sequence i = bytes
+ * [offsets[i], offsets[i+1]).  'A','C','G','T' are bases, every other byte is the
+ * reference's 'X' (cmd/muscato_prep_targets/main.go:68-80).  on_device != 0 means both
+ * pointers are device pointers. */
+int musc_db_load_ascii(musc_ctx* ctx, const char* seqs, const uint64_t* offsets, uint32_t nseq,
+                       int on_device);
+/* Packed form: 2 bits per base (A=0 C=1 G=2 T=3), base j of the concatenated stream in bits
+ * [2j%8, 2j%8+2) of byte j/4; nmask (may be NULL) has 1 bit per base, bit j%8 of byte j/8, set
+ * where the base is 'X' (the 2-bit code under a set mask bit is ignored).  seq_offsets are in
+ * bases, nseq+1 entries.  Host pointers. */
+int musc_db_load_packed(musc_ctx* ctx, const uint8_t* bases2bit, const uint8_t* nmask,
+                        const uint64_t* seq_offsets, uint32_t nseq);
+/* Build the k-mer -> target position index for WindowWidth (done lazily by musc_match if the
+ * width changed).  One-off per (database, width); replaces the per-run Bloom sketch + full
+ * database scan of cmd/muscato_screen/main.go:116-207, 256-366 (result-equivalent: SURVEY.md
+ * 8a note H). */
+int musc_db_build_index(musc_ctx* ctx, int32_t window_width);
+
+/* ---- reads: replaces reading reads_sorted.txt.sz (cmd/muscato_screen/main.go:120-191,
+ * cmd/muscato_window_reads/main.go:94-141).  Reads must already be prepared as the
+ * reference does (non-ACGT -> X, truncated to MaxReadLength, de-duplicated); read_idx in the
+ * hits is the index into this array. --------------------------------------------------- */
+int musc_reads_load_ascii(musc_ctx* ctx, const char* seqs, const uint64_t* offsets,
+                          uint64_t nreads, int on_device);
+int musc_reads_load_packed(musc_ctx* ctx, const uint8_t* bases2bit, const uint8_t* nmask,
+                           const uint64_t* read_offsets, uint64_t nreads);
+
+/* ---- the hot path: screen + confirm (+ per-read best filter) -------------------------
+ * musc_match_device leaves the hits in device memory (count in *nhits);
+ * musc_hits_copy copies them to `dst` (host, or device if dst_on_device) -- capacity in
+ * hits; musc_match = both, into a library-owned host array.  Hit order is unspecified. */
+int musc_match_device(musc_ctx* ctx, const musc_params* params, uint64_t* nhits);
+int musc_hits_copy(musc_ctx* ctx, musc_hit* dst, uint64_t capacity, int dst_on_device);
+int musc_match(musc_ctx* ctx, const musc_params* params, musc_hit** hits, uint64_t* nhits);
+void musc_free_hits(musc_hit* hits);
+
+int musc_get_stats(musc_ctx* ctx, musc_stats* out);
+
+/* ---- several GPUs in one process (a Go host driving one ctx per GPU from locked threads):
+ * concatenate the device-resident hits of ctxs[0..n) in rank order into one host array,
+ * adding read_base[i] to the read_idx of shard i.  (The one-process-per-GPU path gathers
+ * over RCCL instead: muscato_amd/dist.py.) */
+int musc_gather(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hit** hits,
+                uint64_t* nhits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSCATO_HIP_H */

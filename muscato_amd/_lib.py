@@ -1,0 +1,97 @@
+"""ctypes loader of libmuscato_hip.so.  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmuscato_hip.so")
+
+MUSC_MAX_WINDOWS = 16
+
+
+class MuscHit(ctypes.Structure):
+    _fields_ = [("read_idx", ctypes.c_uint32), ("gene_idx", ctypes.c_uint32),
+                ("pos", ctypes.c_uint32), ("nmiss", ctypes.c_uint32)]
+
+
+class MuscParams(ctypes.Structure):
+    _fields_ = [
+        ("n_windows", ctypes.c_int32),
+        ("windows", ctypes.c_int32 * MUSC_MAX_WINDOWS),
+        ("window_width", ctypes.c_int32),
+        ("pmatch", ctypes.c_double),
+        ("min_dinuc", ctypes.c_int32),
+        ("max_read_length", ctypes.c_int32),
+        ("max_matches", ctypes.c_int32),
+        ("match_mode", ctypes.c_int32),
+        ("mmtol", ctypes.c_int32),
+        ("apply_mmtol", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 5),
+    ]
+
+
+class MuscStats(ctypes.Structure):
+    _fields_ = [
+        ("n_reads", ctypes.c_uint64), ("n_read_windows", ctypes.c_uint64),
+        ("n_pairs", ctypes.c_uint64), ("n_accepted", ctypes.c_uint64),
+        ("n_hits", ctypes.c_uint64), ("n_overflow_blocks", ctypes.c_uint64),
+        ("confirm_bytes", ctypes.c_uint64),
+        ("confirm_launches", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),
+        ("ms_seed", ctypes.c_float), ("ms_scan", ctypes.c_float), ("ms_expand", ctypes.c_float),
+        ("ms_confirm", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_total", ctypes.c_float),
+        ("ms_index_build", ctypes.c_float), ("ms_reserved", ctypes.c_float),
+    ]
+
+
+# every symbol include/muscato_hip.h declares
+SYMBOLS = [
+    "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error",
+    "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
+    "musc_reads_load_ascii", "musc_reads_load_packed",
+    "musc_match_device", "musc_hits_copy", "musc_match", "musc_free_hits",
+    "musc_get_stats", "musc_gather",
+]
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raise (never fall back) if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "muscato_amd: %s is missing -- build it with `python -m muscato_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise ImportError("muscato_amd: %s does not export %s" % (LIB_PATH, s))
+    vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32
+    lib.musc_abi_version.restype = ctypes.c_int
+    lib.musc_init.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    lib.musc_destroy.argtypes = [vp]
+    lib.musc_destroy.restype = None
+    lib.musc_last_error.argtypes = [vp]
+    lib.musc_last_error.restype = ctypes.c_char_p
+    lib.musc_db_load_ascii.argtypes = [vp, vp, vp, ctypes.c_uint32, ctypes.c_int]
+    lib.musc_db_load_packed.argtypes = [vp, vp, vp, vp, ctypes.c_uint32]
+    lib.musc_db_build_index.argtypes = [vp, i32]
+    lib.musc_reads_load_ascii.argtypes = [vp, vp, vp, u64, ctypes.c_int]
+    lib.musc_reads_load_packed.argtypes = [vp, vp, vp, vp, u64]
+    lib.musc_match_device.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(u64)]
+    lib.musc_hits_copy.argtypes = [vp, vp, u64, ctypes.c_int]
+    lib.musc_match.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.musc_free_hits.argtypes = [vp]
+    lib.musc_free_hits.restype = None
+    lib.musc_get_stats.argtypes = [vp, ctypes.POINTER(MuscStats)]
+    lib.musc_gather.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(u64),
+                                ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
+                 "musc_reads_load_ascii", "musc_reads_load_packed", "musc_match_device",
+                 "musc_hits_copy", "musc_match", "musc_get_stats", "musc_gather"):
+        getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib

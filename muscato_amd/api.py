@@ -1,0 +1,252 @@
+"""Host-side binding of the hot path: utils.Config mirror + one Engine per GPU.
+
+The reference's interface for this path is the pair of executables
+``muscato_screen config.json`` / ``muscato_confirm config.json k``
+(cmd/muscato/main.go:306-316, 387-420) driven by ``utils.Config``
+(utils/config.go:10-101).  ``Config`` keeps the same field names, JSON form
+and defaults; ``Engine`` is the in-process replacement of the two executables
+plus the sort between them, through the C ABI of include/muscato_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+from dataclasses import dataclass, field, asdict
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+class MuscatoError(RuntimeError):
+    pass
+
+
+@dataclass
+class Config:
+    """utils/config.go:10-101 -- same names; defaults of cmd/muscato/main.go:833-904."""
+    ReadFileName: str = ""
+    GeneFileName: str = ""
+    GeneIdFileName: str = ""
+    ResultsFileName: str = ""
+    Windows: List[int] = field(default_factory=list)
+    WindowWidth: int = 0
+    BloomSize: int = 0
+    NumHash: int = 0
+    PMatch: float = 0.0
+    MinDinuc: int = 0
+    TempDir: str = ""
+    LogDir: str = ""
+    MinReadLength: int = 0
+    MaxReadLength: int = 0
+    MaxMatches: int = 0
+    MaxConfirmProcs: int = 0
+    MMTol: int = 0
+    MatchMode: str = ""
+    SortPar: int = 0
+    SortTemp: str = ""
+    SortMem: str = ""
+    NoCleanTemp: bool = False
+    CPUProfile: bool = False
+
+    @classmethod
+    def from_json(cls, text) -> "Config":
+        d = json.loads(text) if isinstance(text, (str, bytes)) else dict(text)
+        c = cls()
+        for k, v in d.items():
+            if hasattr(c, k) and v is not None:
+                setattr(c, k, v)
+        return c
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self))
+
+    def with_defaults(self) -> "Config":
+        """checkArgs (cmd/muscato/main.go:833-904) for the fields the hot path reads."""
+        c = Config(**asdict(self))
+        if not c.Windows:
+            raise MuscatoError("Windows not provided")
+        if c.WindowWidth == 0:
+            raise MuscatoError("WindowWidth not provided")
+        if c.MaxReadLength == 0:
+            raise MuscatoError("MaxReadLength not provided")
+        if c.BloomSize == 0:
+            c.BloomSize = 4 * 1000 * 1000 * 1000
+        if c.NumHash == 0:
+            c.NumHash = 20
+        if c.PMatch == 0:
+            c.PMatch = 1.0
+        if c.MaxMatches == 0:
+            c.MaxMatches = 1000 * 1000
+        if c.MaxConfirmProcs == 0:
+            c.MaxConfirmProcs = 3
+        if c.MatchMode == "":
+            c.MatchMode = "best"
+        if c.MatchMode not in ("best", "first"):
+            raise MuscatoError("MatchMode must be 'first' or 'best'")
+        if c.ResultsFileName == "":
+            c.ResultsFileName = "results.txt"
+        return c
+
+    def to_params(self, apply_mmtol: bool) -> _lib.MuscParams:
+        c = self.with_defaults()
+        if len(c.Windows) > _lib.MUSC_MAX_WINDOWS:
+            raise MuscatoError("at most %d windows are supported" % _lib.MUSC_MAX_WINDOWS)
+        p = _lib.MuscParams()
+        p.n_windows = len(c.Windows)
+        for i, w in enumerate(c.Windows):
+            p.windows[i] = int(w)
+        p.window_width = int(c.WindowWidth)
+        p.pmatch = float(c.PMatch)
+        p.min_dinuc = int(c.MinDinuc)
+        p.max_read_length = int(c.MaxReadLength)
+        p.max_matches = int(c.MaxMatches)
+        p.match_mode = 1 if c.MatchMode == "first" else 0
+        p.mmtol = int(c.MMTol)
+        p.apply_mmtol = 1 if apply_mmtol else 0
+        return p
+
+
+def concat(seqs: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    """list of ASCII sequences -> (uint8 buffer, uint64 offsets[n+1])."""
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(seqs) + b"\0" * 8, dtype=np.uint8).copy()
+    return buf, off
+
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+
+
+def pack_2bit(buf: np.ndarray, nbases: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """ASCII bases -> the packed ABI form: 2 bits per base (A0 C1 G2 T3), 4 bases per
+    byte little-endian, plus a 1-bit-per-base X mask (None if there is no X)."""
+    codes = _CODE[buf[:nbases]]
+    isx = codes == 255
+    codes = np.where(isx, 0, codes).astype(np.uint8)
+    pad = (-nbases) % 4
+    c4 = np.concatenate([codes, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    packed = (c4[:, 0] | (c4[:, 1] << 2) | (c4[:, 2] << 4) | (c4[:, 3] << 6)).astype(np.uint8)
+    mask = np.packbits(isx, bitorder="little") if isx.any() else None
+    return packed, mask
+
+
+class Engine:
+    """One context per GPU: resident target database + index, resident reads, match()."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.musc_init(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise MuscatoError("musc_init failed: %s" % self._lib.musc_last_error(None).decode())
+        self._h = h
+        self.device = device
+        self.n_targets = 0
+        self.n_reads = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.musc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise MuscatoError("%s failed (%d): %s" % (what, rc, self._lib.musc_last_error(self._h).decode()))
+
+    # ---- database (gene number = index in the list = line index of GeneFileName)
+    def load_targets(self, seqs: Sequence[bytes]) -> None:
+        buf, off = concat(seqs)
+        self.load_targets_arrays(buf, off)
+
+    def load_targets_arrays(self, buf: np.ndarray, off: np.ndarray) -> None:
+        self._check(self._lib.musc_db_load_ascii(self._h, buf.ctypes.data, off.ctypes.data, len(off) - 1, 0),
+                    "musc_db_load_ascii")
+        self.n_targets = len(off) - 1
+
+    def load_targets_device(self, seqs_ptr: int, off_ptr: int, nseq: int) -> None:
+        self._check(self._lib.musc_db_load_ascii(self._h, seqs_ptr, off_ptr, nseq, 1), "musc_db_load_ascii")
+        self.n_targets = nseq
+
+    def load_targets_packed(self, seqs: Sequence[bytes]) -> None:
+        buf, off = concat(seqs)
+        packed, mask = pack_2bit(buf, int(off[-1]))
+        packed = np.concatenate([packed, np.zeros(8, np.uint8)])
+        mp = mask.ctypes.data if mask is not None else None
+        self._check(self._lib.musc_db_load_packed(self._h, packed.ctypes.data, mp, off.ctypes.data, len(off) - 1),
+                    "musc_db_load_packed")
+        self.n_targets = len(off) - 1
+
+    def build_index(self, window_width: int) -> None:
+        self._check(self._lib.musc_db_build_index(self._h, int(window_width)), "musc_db_build_index")
+
+    # ---- reads (already prepared: X-substituted, truncated, unique)
+    def load_reads(self, seqs: Sequence[bytes]) -> None:
+        buf, off = concat(seqs)
+        self.load_reads_arrays(buf, off)
+
+    def load_reads_arrays(self, buf: np.ndarray, off: np.ndarray) -> None:
+        self._check(self._lib.musc_reads_load_ascii(self._h, buf.ctypes.data, off.ctypes.data, len(off) - 1, 0),
+                    "musc_reads_load_ascii")
+        self.n_reads = len(off) - 1
+
+    def load_reads_device(self, seqs_ptr: int, off_ptr: int, nreads: int) -> None:
+        self._check(self._lib.musc_reads_load_ascii(self._h, seqs_ptr, off_ptr, nreads, 1), "musc_reads_load_ascii")
+        self.n_reads = nreads
+
+    def load_reads_packed(self, seqs: Sequence[bytes]) -> None:
+        buf, off = concat(seqs)
+        packed, mask = pack_2bit(buf, int(off[-1]))
+        packed = np.concatenate([packed, np.zeros(8, np.uint8)])
+        mp = mask.ctypes.data if mask is not None else None
+        self._check(self._lib.musc_reads_load_packed(self._h, packed.ctypes.data, mp, off.ctypes.data, len(off) - 1),
+                    "musc_reads_load_packed")
+        self.n_reads = len(off) - 1
+
+    # ---- hot path
+    def match_device(self, cfg: Config, apply_mmtol: bool = True) -> int:
+        """Run screen+confirm(+select); hits stay on the device.  Returns the hit count."""
+        p = cfg.to_params(apply_mmtol)
+        n = ctypes.c_uint64()
+        self._check(self._lib.musc_match_device(self._h, ctypes.byref(p), ctypes.byref(n)), "musc_match_device")
+        return int(n.value)
+
+    def hits_to(self, ptr: int, capacity: int, on_device: bool) -> None:
+        self._check(self._lib.musc_hits_copy(self._h, ptr, capacity, 1 if on_device else 0), "musc_hits_copy")
+
+    def match(self, cfg: Config, apply_mmtol: bool = True) -> np.ndarray:
+        """-> uint32 array [n, 4] of (read_idx, gene_idx, pos, nmiss), order unspecified."""
+        n = self.match_device(cfg, apply_mmtol)
+        out = np.zeros((n, 4), dtype=np.uint32)
+        if n:
+            self.hits_to(out.ctypes.data, n, False)
+        return out
+
+    def stats(self) -> dict:
+        s = _lib.MuscStats()
+        self._check(self._lib.musc_get_stats(self._h, ctypes.byref(s)), "musc_get_stats")
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+
+def sorted_hits(a: np.ndarray) -> np.ndarray:
+    """Canonical order (read, gene, pos, nmiss) for comparisons."""
+    if len(a) == 0:
+        return a.reshape(0, 4)
+    idx = np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0]))
+    return a[idx]

@@ -1,0 +1,1322 @@
+// libmuscato_hip.so -- muscato's seed-and-extend hot path on MI355X (gfx950, wave64).
+//
+// Path (reference file:line, kshedden/muscato):
+//   screen : cmd/muscato_screen/main.go:116-207 (read k-mer sketch), :256-366 (target scan)
+//   join   : cmd/muscato/main.go:318-385 (sort) + cmd/muscato_confirm/main.go:375-416 (merge)
+//   confirm: cmd/muscato_confirm/main.go:151-159 (cdiff), :171-250 (searchpairs)
+//   select : cmd/muscato_combine_windows/main.go:36-60 (per-read best + MMTol)
+//
+// MI355X design: the target database stays resident in HBM as one 2-bit
+// stream plus a k-mer -> (gene, offset) CSR index built once per (database, WindowWidth);
+// reads are fixed-stride 2-bit records.  One pass = k_seed (window keys -> index buckets)
+// -> scan -> k_expand (candidate pairs) -> k_confirm (XOR/popcount Hamming distance,
+// HBM-bound) -> k_select (per-read best + MMTol, compaction).  The Bloom sketch of the
+// reference only prunes work and cannot change results (SURVEY.md 8a note H): every
+// candidate is verified exactly in k_confirm, including its window key.
+//
+// There is no CPU fallback in this library.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/muscato_hip.h"
+
+// ------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------
+
+#define DEV __device__ __forceinline__
+
+DEV uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// 64 bits of a little-endian bit stream held in u32 words, starting at bit `bo`.
+DEV uint64_t ext64(const uint32_t* __restrict__ w, uint64_t bo) {
+  const uint64_t i = bo >> 5;
+  const uint32_t sh = (uint32_t)bo & 31u;
+  const uint64_t lo = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
+  if (sh == 0) return lo;
+  return (lo >> sh) | ((uint64_t)w[i + 2] << (64 - sh));
+}
+
+DEV uint64_t lowmask64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// Index bucket of the ww-base window starting at bit `bo` of plane w (mask plane m or null).
+// Identity when the key fits the table and holds no X (exact, no false candidates);
+// otherwise a 64-bit mix.  Any deterministic function is correct: k_confirm re-verifies
+// the window bases, so collisions only cost extra pairs.
+DEV uint32_t bucket_of(const uint32_t* __restrict__ w, const uint32_t* __restrict__ m, uint64_t bo,
+                       int ww, int bits, int direct) {
+  const int nb = 2 * ww;
+  uint64_t h = 0, anymask = 0, key0 = 0;
+  for (int c = 0; c < nb; c += 64) {
+    const int take = nb - c < 64 ? nb - c : 64;
+    const uint64_t key = ext64(w, bo + c) & lowmask64(take);
+    const uint64_t mk = m ? (ext64(m, bo + c) & lowmask64(take)) : 0ull;
+    if (c == 0) key0 = key;
+    anymask |= mk;
+    h = mix64(h ^ key ^ mix64(mk + 0x9E3779B97F4A7C15ull * (uint64_t)(c + 1)));
+  }
+  if (direct && anymask == 0) return (uint32_t)key0;
+  return (uint32_t)(h >> (64 - bits));
+}
+
+// ------------------------------------------------------------------------------------
+// packing kernels (ASCII / 2-bit stream -> device layout)
+// ------------------------------------------------------------------------------------
+
+DEV uint32_t ascii_code(unsigned char c, uint32_t* isx) {
+  const uint32_t a = c == 'A', cc = c == 'C', g = c == 'G', t = c == 'T';
+  *isx = !(a | cc | g | t);
+  return cc | (g << 1) | (t * 3u);
+}
+
+// one thread per u32 word (16 bases) of the database stream
+__global__ void k_pack_db_ascii(const unsigned char* __restrict__ s, uint64_t nbases,
+                                uint32_t* __restrict__ db2, uint32_t* __restrict__ dbm2,
+                                uint64_t nwords, uint32_t* __restrict__ has_x) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint32_t v = 0, mv = 0;
+  const uint64_t b0 = w * 16;
+  for (int j = 0; j < 16; j++) {
+    const uint64_t b = b0 + j;
+    if (b < nbases) {
+      uint32_t isx;
+      const uint32_t c = ascii_code(s[b], &isx);
+      v |= c << (2 * j);
+      mv |= isx << (2 * j);
+    }
+  }
+  db2[w] = v;
+  dbm2[w] = mv;
+  if (mv) atomicOr(has_x, 1u);
+}
+
+// 2-bit stream + optional 1-bit mask (ABI packed form) -> internal planes
+__global__ void k_pack_db_packed(const uint32_t* __restrict__ in2, const uint16_t* __restrict__ inm,
+                                 uint32_t* __restrict__ db2, uint32_t* __restrict__ dbm2,
+                                 uint64_t nwords, uint32_t* __restrict__ has_x) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint32_t mv = 0;
+  if (inm) {
+    const uint32_t m16 = inm[w];
+    for (int j = 0; j < 16; j++) mv |= ((m16 >> j) & 1u) << (2 * j);
+  }
+  db2[w] = in2[w] & ~(mv | (mv << 1));
+  dbm2[w] = mv;
+  if (mv) atomicOr(has_x, 1u);
+}
+
+__global__ void k_max_len(const uint64_t* __restrict__ off, uint64_t n, unsigned long long* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long l = 0;
+  if (i < n) l = off[i + 1] - off[i];
+  for (int d = 32; d; d >>= 1) {
+    const unsigned long long o = __shfl_xor(l, d);
+    l = o > l ? o : l;
+  }
+  if ((threadIdx.x & 63) == 0 && l) atomicMax(out, l);
+}
+
+// one thread per (read, record word).  Record = rw u32 words: bases in words 0..rw-2
+// (2 bits each, zero filled past the read), word rw-1 = len | valid_windows << 16.
+template <bool PACKED>
+__global__ void k_pack_reads(const unsigned char* __restrict__ s, const uint32_t* __restrict__ in2,
+                             const uint32_t* __restrict__ inm, const uint64_t* __restrict__ off,
+                             uint64_t nreads, int rw, uint32_t* __restrict__ rd,
+                             uint32_t* __restrict__ rdm, uint32_t* __restrict__ has_x) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t r = t / rw;
+  const int j = (int)(t % rw);
+  if (r >= nreads) return;
+  const uint64_t o = off[r];
+  const uint32_t len = (uint32_t)(off[r + 1] - o);
+  if (j == rw - 1) {
+    rd[t] = len & 0xFFFFu;
+    rdm[t] = 0;
+    return;
+  }
+  uint32_t v = 0, mv = 0;
+  for (int b = 0; b < 16; b++) {
+    const uint32_t q = (uint32_t)j * 16 + b;
+    if (q < len) {
+      uint32_t c, isx;
+      if (PACKED) {
+        const uint64_t g = o + q;
+        c = (in2[g >> 4] >> ((g & 15) * 2)) & 3u;
+        isx = inm ? ((inm[g >> 5] >> (g & 31)) & 1u) : 0u;
+        if (isx) c = 0;
+      } else {
+        c = ascii_code(s[o + q], &isx);
+      }
+      v |= c << (2 * b);
+      mv |= isx << (2 * b);
+    }
+  }
+  rd[t] = v;
+  rdm[t] = mv;
+  if (mv) atomicOr(has_x, 1u);
+}
+
+// ------------------------------------------------------------------------------------
+// exclusive / inclusive scan (u32), 2048 items per 256-thread block
+// ------------------------------------------------------------------------------------
+
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+template <bool INCLUSIVE>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t* __restrict__ in,
+                                                          uint32_t* __restrict__ out,
+                                                          uint32_t* __restrict__ block_sums,
+                                                          uint64_t n) {
+  __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = (base + i < n) ? in[base + i] : 0u;
+    sum += v[i];
+  }
+  // wave inclusive scan of the per-thread sums
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_wave[wid] = inc;
+  __syncthreads();
+  uint32_t wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_BLOCK / 64; w++) {
+    if (w < wid) wave_off += s_wave[w];
+    total += s_wave[w];
+  }
+  uint32_t run = wave_off + inc - sum;  // exclusive prefix of this thread
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (INCLUSIVE) run += v[i];
+    if (base + i < n) out[base + i] = run;
+    if (!INCLUSIVE) run += v[i];
+  }
+  if (block_sums && threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ out,
+                                                        const uint32_t* __restrict__ block_off,
+                                                        uint64_t n) {
+  const uint32_t add = block_off[blockIdx.x];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++)
+    if (base + i < n) out[base + i] += add;
+}
+
+// ------------------------------------------------------------------------------------
+// database index: bucket -> list of (gene, window start).  A has 2^bits + 2 counters:
+// counts land in A[b+2]; after an inclusive scan A[b+1] = start(b); the scatter pass
+// bumps A[b+1], leaving A[b] = start(b), A[b+1] = end(b).
+// ------------------------------------------------------------------------------------
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_index(const uint32_t* __restrict__ db2,
+                                               const uint32_t* __restrict__ dbm2,
+                                               const uint64_t* __restrict__ seq_off, uint32_t nseq,
+                                               uint64_t nbases, int ww, int bits, int direct,
+                                               uint32_t* __restrict__ A, uint2* __restrict__ entries) {
+  __shared__ uint32_t s_g0;
+  const uint64_t gfirst = (uint64_t)blockIdx.x * blockDim.x;
+  if (threadIdx.x == 0) {
+    uint32_t lo = 0, hi = nseq;  // largest i < nseq with seq_off[i] <= gfirst
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (seq_off[mid] <= gfirst) lo = mid; else hi = mid;
+    }
+    s_g0 = lo;
+  }
+  __syncthreads();
+  const uint64_t g = gfirst + threadIdx.x;
+  if (g >= nbases) return;
+  uint32_t gene = s_g0;
+  while (seq_off[gene + 1] <= g) gene++;
+  const uint64_t s = seq_off[gene], e = seq_off[gene + 1];
+  const uint64_t jx = g - s;
+  if (jx + (uint64_t)ww > e - s) return;  // window would cross the target end
+  const uint32_t b = bucket_of(db2, dbm2, 2 * g, ww, bits, direct);
+  if (!SCATTER) {
+    atomicAdd(&A[(uint64_t)b + 2], 1u);
+  } else {
+    const uint32_t slot = atomicAdd(&A[(uint64_t)b + 1], 1u);
+    entries[slot] = make_uint2(gene, (uint32_t)jx);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// hot path kernels
+// ------------------------------------------------------------------------------------
+
+struct PathParams {
+  int32_t W;
+  int32_t win[MUSC_MAX_WINDOWS];
+  int32_t ww;
+  int32_t min_dinuc;
+  int32_t bits;
+  int32_t direct;
+  int32_t mmtol;
+  int32_t apply_mmtol;
+  uint32_t q1zero_mask;  // windows whose start is 0 (the pos-0 path of processSeq)
+};
+
+DEV uint32_t plane_code(const uint32_t* __restrict__ w, const uint32_t* __restrict__ m, uint32_t j) {
+  uint32_t c = (w[j >> 4] >> ((j & 15) * 2)) & 3u;
+  if (m && ((m[j >> 4] >> ((j & 15) * 2)) & 1u)) c = 4;
+  return c;
+}
+
+// utils/entropy.go:5-40 on packed bases: number of distinct adjacent letter pairs over the
+// 5-letter alphabet {A,C,G,T,other}; the count does not depend on how letters are numbered.
+DEV int count_dinuc_packed(const uint32_t* __restrict__ w, const uint32_t* __restrict__ m,
+                           uint32_t q1, int ww) {
+  uint32_t seen = 0;
+  uint32_t prev = plane_code(w, m, q1);
+  for (int i = 1; i < ww; i++) {
+    const uint32_t cur = plane_code(w, m, q1 + i);
+    seen |= 1u << (prev * 5 + cur);
+    prev = cur;
+  }
+  return __popc(seen);
+}
+
+// One thread per read: which windows take part (cmd/muscato_window_reads/main.go:106-118 ==
+// cmd/muscato_screen/main.go:174-185) and which index bucket each one probes.
+__global__ __launch_bounds__(256) void k_seed(uint32_t* __restrict__ rd,
+                                              const uint32_t* __restrict__ rdm, uint64_t r0,
+                                              uint32_t n, int rw, PathParams pp,
+                                              const uint32_t* __restrict__ A,
+                                              uint32_t* __restrict__ wstart,
+                                              uint32_t* __restrict__ wcnt,
+                                              uint32_t* __restrict__ rtot,
+                                              unsigned long long* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nvalid = 0;
+  if (i < n) {
+    const uint64_t r = r0 + i;
+    uint32_t* rec = rd + r * (uint64_t)rw;
+    const uint32_t* recm = rdm ? rdm + r * (uint64_t)rw : nullptr;
+    const uint32_t len = rec[rw - 1] & 0xFFFFu;
+    uint32_t valid = 0, tot = 0;
+    for (int k = 0; k < pp.W; k++) {
+      const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
+      uint32_t s = 0, c = 0;
+      if (len >= q2) {
+        const bool ok = pp.min_dinuc <= 0 || count_dinuc_packed(rec, recm, q1, pp.ww) >= pp.min_dinuc;
+        if (ok) {
+          valid |= 1u << k;
+          const uint32_t b = bucket_of(rec, recm, 2ull * q1, pp.ww, pp.bits, pp.direct);
+          s = A[b];
+          c = A[(uint64_t)b + 1] - s;
+        }
+      }
+      wstart[(uint64_t)i * pp.W + k] = s;
+      wcnt[(uint64_t)i * pp.W + k] = c;
+      tot += c;
+    }
+    rec[rw - 1] = len | (valid << 16);
+    rtot[i] = tot;
+    nvalid = tot;
+  }
+  // 64-bit total of candidate pairs of this launch (the u32 scan could wrap)
+  unsigned long long t64 = nvalid;
+  for (int d = 32; d; d >>= 1) t64 += __shfl_xor(t64, d);
+  if ((threadIdx.x & 63) == 0 && t64) atomicAdd(&counters[3], t64);
+}
+
+#define PAIR_INVALID 0xFFFFFFFFu
+#define NX_REJECT 0xFFFFu
+
+// One thread per read: walk its buckets and write one candidate pair per index entry.
+// The fit rules of cmd/muscato_screen/main.go:294-316 (target position 0, literal 100) and
+// :335-363 + cmd/muscato_confirm/main.go:201-203 (read must end inside the target) are
+// applied here, where the target length is at hand.
+__global__ __launch_bounds__(256) void k_expand(const uint32_t* __restrict__ rd, uint64_t r0,
+                                                uint32_t n, int rw, PathParams pp,
+                                                const uint32_t* __restrict__ wstart,
+                                                const uint32_t* __restrict__ wcnt,
+                                                const uint32_t* __restrict__ rbase,
+                                                const uint2* __restrict__ entries,
+                                                const uint64_t* __restrict__ seq_off,
+                                                uint32_t* __restrict__ p_read,
+                                                uint32_t* __restrict__ p_gpos,
+                                                uint32_t* __restrict__ p_meta,
+                                                uint32_t* __restrict__ p_gene,
+                                                unsigned long long* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nvalid = 0;
+  if (i < n) nvalid = __popc(rd[(r0 + i) * (uint64_t)rw + rw - 1] >> 16);
+  for (int d = 32; d; d >>= 1) nvalid += __shfl_xor(nvalid, d);
+  if ((threadIdx.x & 63) == 0 && nvalid) atomicAdd(&counters[0], (unsigned long long)nvalid);
+  if (i >= n) return;
+  const int64_t len = rd[(r0 + i) * (uint64_t)rw + rw - 1] & 0xFFFFu;
+  uint64_t out = rbase[i];
+  for (int k = 0; k < pp.W; k++) {
+    const uint32_t s = wstart[(uint64_t)i * pp.W + k];
+    const uint32_t c = wcnt[(uint64_t)i * pp.W + k];
+    const int64_t q1 = pp.win[k];
+    for (uint32_t e = 0; e < c; e++) {
+      const uint2 ent = entries[(uint64_t)s + e];
+      const uint64_t go = seq_off[ent.x];
+      const int64_t T = (int64_t)(seq_off[ent.x + 1] - go);
+      const int64_t jx = ent.y;
+      const int64_t p = jx - q1;
+      int64_t lim0 = 100 - pp.ww;  // cmd/muscato_screen/main.go:305 (q1 == 0 there)
+      if (lim0 > T) lim0 = T;
+      const bool fit0 = len <= lim0;
+      bool ok = p >= 0;
+      if (jx == 0) ok = ok && fit0; else ok = ok && (p + len <= T);
+      const uint32_t z = (p == 0 && !fit0) ? 1u : 0u;
+      const uint64_t gpos = go + (uint64_t)(p > 0 ? p : 0);
+      p_read[out] = ok ? i : PAIR_INVALID;
+      p_gpos[out] = (uint32_t)gpos;
+      p_meta[out] = (uint32_t)k | (z << 4) | ((uint32_t)(gpos >> 32) << 8);
+      p_gene[out] = ent.x;
+      out++;
+    }
+  }
+}
+
+// u32 mask of the bits of window [q1, q1+ww) (2 bits per base) that fall in record word j
+DEV uint32_t window_word_mask(int q1, int ww, int j) {
+  const int lo = 2 * q1 - 32 * j, hi = lo + 2 * ww;
+  if (hi <= 0 || lo >= 32) return 0u;
+  const uint32_t mh = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+  const uint32_t ml = lo <= 0 ? 0xFFFFFFFFu : ~((1u << lo) - 1u);
+  return mh & ml;
+}
+
+// 16 bytes at a dword-aligned address (global memory allows it on gfx950)
+struct __attribute__((packed, aligned(4))) u32x4_u {
+  uint32_t x, y, z, w;
+};
+
+// The confirm kernel: one lane per candidate pair.  Loads the 2-bit read record (aligned,
+// neighbouring lanes mostly share it) and the target span at an arbitrary base offset
+// (dword-aligned 16-byte gathers + funnel shift), XOR + popcount = cdiff over the whole read
+// (cmd/muscato_confirm/main.go:151-159, 205-211; X==X through the mask plane), then decides
+// whether THIS window is the first window of the read that the reference would have emitted
+// the tuple through (exact window key + fit), which makes the union over windows a set
+// without a sort.  RW = record words (compile time) or 0 = runtime stride.
+template <int RW, bool MASK>
+__global__ __launch_bounds__(256) void k_confirm(
+    const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
+    const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, int rw_rt,
+    PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint32_t* __restrict__ p_read,
+    const uint32_t* __restrict__ p_gpos, const uint32_t* __restrict__ p_meta,
+    uint16_t* __restrict__ p_nx, uint64_t npairs) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npairs) return;
+  const uint32_t ri = p_read[idx];
+  if (ri == PAIR_INVALID) {
+    p_nx[idx] = NX_REJECT;
+    return;
+  }
+  const int rw = RW ? RW : rw_rt;
+  const uint32_t meta = p_meta[idx];
+  const uint64_t gpos = (uint64_t)p_gpos[idx] | ((uint64_t)((meta >> 8) & 0xFFu) << 32);
+  const uint32_t k = meta & 15u, z = (meta >> 4) & 1u;
+  const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)rw;
+  const uint64_t widx = gpos >> 4;
+  const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
+
+  uint32_t nx = 0, rmeta, exact;
+  if constexpr (RW != 0) {
+    // ---- static stride: whole record and span in registers, 16-byte loads
+    uint32_t r[RW], t[RW], rm[RW], tm[RW];
+#pragma unroll
+    for (int q = 0; q < RW / 4; q++) {
+      const uint4 a = *reinterpret_cast<const uint4*>(rec + 4 * q);
+      r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
+      const u32x4_u b = *reinterpret_cast<const u32x4_u*>(db2 + widx + 4 * q);
+      t[4 * q] = b.x; t[4 * q + 1] = b.y; t[4 * q + 2] = b.z; t[4 * q + 3] = b.w;
+      if (MASK) {
+        const uint4 c = *reinterpret_cast<const uint4*>(rdm + (r0 + ri) * (uint64_t)rw + 4 * q);
+        rm[4 * q] = c.x; rm[4 * q + 1] = c.y; rm[4 * q + 2] = c.z; rm[4 * q + 3] = c.w;
+        const u32x4_u d = *reinterpret_cast<const u32x4_u*>(dbm2 + widx + 4 * q);
+        tm[4 * q] = d.x; tm[4 * q + 1] = d.y; tm[4 * q + 2] = d.z; tm[4 * q + 3] = d.w;
+      }
+    }
+    rmeta = r[RW - 1];
+    const int len2 = 2 * (int)(rmeta & 0xFFFFu);
+    exact = rmeta >> 16;
+    if (z) exact &= ~pp.q1zero_mask;
+#pragma unroll
+    for (int j = 0; j < RW - 1; j++) {
+      const uint32_t tj = __funnelshift_r(t[j], t[j + 1], sh);
+      const uint32_t x = r[j] ^ tj;
+      uint32_t d = (x | (x >> 1)) & 0x55555555u;
+      if (MASK) d |= (rm[j] ^ __funnelshift_r(tm[j], tm[j + 1], sh)) & 0x55555555u;
+      const int rem = len2 - 32 * j;
+      d &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+      nx += __popc(d);
+      for (int kk = 0; kk < pp.W; kk++)
+        if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
+    }
+  } else {
+    // ---- runtime stride (reads longer than the compiled strides): streaming words
+    rmeta = rec[rw - 1];
+    const int len2 = 2 * (int)(rmeta & 0xFFFFu);
+    exact = rmeta >> 16;
+    if (z) exact &= ~pp.q1zero_mask;
+    const uint32_t* __restrict__ recm = MASK ? rdm + (r0 + ri) * (uint64_t)rw : nullptr;
+    uint32_t tlo = db2[widx], tmlo = MASK ? dbm2[widx] : 0u;
+    for (int j = 0; j < rw - 1; j++) {
+      const uint32_t thi = db2[widx + j + 1];
+      const uint32_t x = rec[j] ^ __funnelshift_r(tlo, thi, sh);
+      tlo = thi;
+      uint32_t d = (x | (x >> 1)) & 0x55555555u;
+      if (MASK) {
+        const uint32_t tmhi = dbm2[widx + j + 1];
+        d |= (recm[j] ^ __funnelshift_r(tmlo, tmhi, sh)) & 0x55555555u;
+        tmlo = tmhi;
+      }
+      const int rem = len2 - 32 * j;
+      d &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+      nx += __popc(d);
+      for (int kk = 0; kk < pp.W; kk++)
+        if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
+    }
+  }
+  const uint32_t kmin = exact ? (uint32_t)(__ffs(exact) - 1) : 0xFFu;
+  const bool ok = (kmin == k) && (nx <= nmiss_tab[rmeta & 0xFFFFu]);
+  p_nx[idx] = ok ? (uint16_t)nx : (uint16_t)NX_REJECT;
+}
+
+// One thread per read: best mismatch count over its accepted pairs, then emit the tuples
+// with nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60), or all accepted
+// tuples when apply_mmtol == 0.
+__global__ __launch_bounds__(256) void k_select(uint64_t r0, uint32_t n, PathParams pp,
+                                                const uint32_t* __restrict__ rbase,
+                                                const uint32_t* __restrict__ p_gpos,
+                                                const uint32_t* __restrict__ p_meta,
+                                                const uint32_t* __restrict__ p_gene,
+                                                const uint16_t* __restrict__ p_nx,
+                                                const uint64_t* __restrict__ seq_off,
+                                                musc_hit* __restrict__ hits,
+                                                unsigned long long* __restrict__ counters) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t acc = 0;
+  if (i < n) {
+    const uint64_t b = rbase[i], e = rbase[i + 1];
+    uint32_t best = NX_REJECT;
+    for (uint64_t j = b; j < e; j++) {
+      const uint32_t v = p_nx[j];
+      best = v < best ? v : best;
+    }
+    if (best != NX_REJECT) {
+      const uint32_t thr = pp.apply_mmtol ? best + (uint32_t)pp.mmtol : NX_REJECT - 1;
+      for (uint64_t j = b; j < e; j++) {
+        const uint32_t v = p_nx[j];
+        if (v == NX_REJECT) continue;
+        acc++;
+        if (v <= thr) {
+          const unsigned long long slot = atomicAdd(&counters[2], 1ull);
+          const uint32_t gene = p_gene[j];
+          const uint64_t gpos = (uint64_t)p_gpos[j] | ((uint64_t)((p_meta[j] >> 8) & 0xFFu) << 32);
+          musc_hit h;
+          h.read_idx = (uint32_t)(r0 + i);
+          h.gene_idx = gene;
+          h.pos = (uint32_t)(gpos - seq_off[gene]);
+          h.nmiss = v;
+          hits[slot] = h;
+        }
+      }
+    }
+  }
+  for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&counters[1], (unsigned long long)acc);
+}
+
+__global__ void k_rebase_hits(musc_hit* h, uint64_t n, uint32_t add) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) h[i].read_idx += add;
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+
+namespace {
+
+std::string g_init_error;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  uint64_t cap = 0;  // elements
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct musc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // database
+  uint32_t* db2 = nullptr;
+  uint32_t* dbm2 = nullptr;  // null when the database holds no X
+  uint64_t* seq_off = nullptr;
+  uint32_t nseq = 0;
+  uint64_t nbases = 0;
+  uint64_t db_words = 0;
+
+  // index
+  int idx_ww = 0, idx_bits = 0, idx_direct = 0;
+  uint32_t* idx_A = nullptr;
+  uint2* idx_entries = nullptr;
+  uint64_t idx_n = 0;
+
+  // reads
+  uint32_t* rd = nullptr;
+  uint32_t* rdm = nullptr;  // null when no read holds an X
+  uint64_t nreads = 0;
+  int rw = 0;
+  uint32_t max_len = 0;
+
+  // per-batch work buffers
+  DevBuf<uint32_t> wstart, wcnt, rtot, rbase, scan_tmp;
+  DevBuf<uint32_t> p_read, p_gpos, p_meta, p_gene;
+  DevBuf<uint16_t> p_nx;
+  DevBuf<uint16_t> nmiss_tab;
+  unsigned long long* counters = nullptr;  // [0] valid windows [1] accepted [2] hit cursor
+  uint64_t* h_pinned = nullptr;            // 4 x u64 pinned staging
+
+  DevBuf<musc_hit> hits;
+  uint64_t nhits = 0;
+
+  uint32_t batch_reads = 4u << 20;
+  musc_stats stats;
+};
+
+namespace {
+
+int fail(musc_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_init_error = buf;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                 \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail((c), 10, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+int ensure(musc_ctx* c, DevBuf<T>& b, uint64_t n, bool keep = false) {
+  if (n <= b.cap && b.p) return 0;
+  uint64_t ncap = std::max<uint64_t>(n, b.cap + b.cap / 2);
+  ncap = std::max<uint64_t>(ncap, 1024);
+  T* np = nullptr;
+  HIPCHK(c, hipMalloc((void**)&np, ncap * sizeof(T) + 64));
+  if (keep && b.p && b.cap) {
+    hipError_t e = hipMemcpyAsync(np, b.p, b.cap * sizeof(T), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(np);
+      return fail(c, 10, "hit buffer grow failed: %s", hipGetErrorString(e));
+    }
+  }
+  b.release();
+  b.p = np;
+  b.cap = ncap;
+  return 0;
+}
+
+inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+// u32 scan of n elements (in may equal out).  tmp must hold scan_tmp_elems(n).
+uint64_t scan_tmp_elems(uint64_t n) {
+  uint64_t t = 0;
+  while (n > SCAN_TILE) {
+    n = (n + SCAN_TILE - 1) / SCAN_TILE;
+    t += n + 8;
+  }
+  return t + 8;
+}
+
+int scan_u32(musc_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, bool inclusive, uint32_t* tmp) {
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb > 0x7FFFFFFFull) return fail(c, 11, "scan too large");
+  if (nb <= 1) {
+    if (inclusive) hipLaunchKernelGGL(k_scan_block<true>, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, in, out, (uint32_t*)nullptr, n);
+    else hipLaunchKernelGGL(k_scan_block<false>, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, in, out, (uint32_t*)nullptr, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  uint32_t* sums = tmp;
+  if (inclusive) hipLaunchKernelGGL(k_scan_block<true>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, out, sums, n);
+  else hipLaunchKernelGGL(k_scan_block<false>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, out, sums, n);
+  HIPCHK(c, hipGetLastError());
+  int rc = scan_u32(c, sums, sums, nb, false, tmp + nb + 8);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, out, sums, n);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+void free_index(musc_ctx* c) {
+  if (c->idx_A) (void)hipFree(c->idx_A);
+  if (c->idx_entries) (void)hipFree(c->idx_entries);
+  c->idx_A = nullptr;
+  c->idx_entries = nullptr;
+  c->idx_ww = 0;
+  c->idx_n = 0;
+}
+
+void free_db(musc_ctx* c) {
+  free_index(c);
+  if (c->db2) (void)hipFree(c->db2);
+  if (c->dbm2) (void)hipFree(c->dbm2);
+  if (c->seq_off) (void)hipFree(c->seq_off);
+  c->db2 = c->dbm2 = nullptr;
+  c->seq_off = nullptr;
+  c->nseq = 0;
+  c->nbases = 0;
+}
+
+void free_reads(musc_ctx* c) {
+  if (c->rd) (void)hipFree(c->rd);
+  if (c->rdm) (void)hipFree(c->rdm);
+  c->rd = c->rdm = nullptr;
+  c->nreads = 0;
+  c->rw = 0;
+}
+
+struct EvPair {
+  hipEvent_t a, b;
+};
+
+struct Timer {
+  musc_ctx* c;
+  std::vector<EvPair> ev[5];
+  explicit Timer(musc_ctx* ctx) : c(ctx) {}
+  int begin(int fam) {
+    EvPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return 1;
+    (void)hipEventRecord(p.a, c->stream);
+    ev[fam].push_back(p);
+    return 0;
+  }
+  void end(int fam) { (void)hipEventRecord(ev[fam].back().b, c->stream); }
+  float total(int fam) {
+    float t = 0;
+    for (auto& p : ev[fam]) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) t += ms;
+    }
+    return t;
+  }
+  ~Timer() {
+    for (auto& v : ev)
+      for (auto& p : v) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+      }
+  }
+};
+
+int check_params(musc_ctx* c, const musc_params* P) {
+  if (!P) return fail(c, 2, "params is NULL");
+  if (P->n_windows < 1 || P->n_windows > MUSC_MAX_WINDOWS)
+    return fail(c, 2, "n_windows=%d outside 1..%d", P->n_windows, MUSC_MAX_WINDOWS);
+  if (P->window_width < 1 || P->window_width > 4096) return fail(c, 2, "bad window_width=%d", P->window_width);
+  for (int k = 0; k < P->n_windows; k++)
+    if (P->windows[k] < 0 || P->windows[k] > 60000) return fail(c, 2, "bad window start %d", P->windows[k]);
+  if (!(P->pmatch >= 0.0 && P->pmatch <= 1.0)) return fail(c, 2, "PMatch=%g outside [0,1]", P->pmatch);
+  if (P->match_mode != 0 && P->match_mode != 1) return fail(c, 2, "match_mode must be 0 (best) or 1 (first)");
+  if (P->mmtol < 0) return fail(c, 2, "MMTol < 0");
+  return 0;
+}
+
+template <int RW>
+void launch_confirm(musc_ctx* c, bool mask, uint64_t r0, const PathParams& pp, uint64_t npairs) {
+  const dim3 grid(nblk(npairs, 256)), block(256);
+  if (mask)
+    hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
+                       c->rw, pp, c->nmiss_tab.p, c->p_read.p, c->p_gpos.p, c->p_meta.p, c->p_nx.p, npairs);
+  else
+    hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
+                       c->rw, pp, c->nmiss_tab.p, c->p_read.p, c->p_gpos.p, c->p_meta.p, c->p_nx.p, npairs);
+}
+
+}  // namespace
+
+extern "C" {
+
+int musc_abi_version(void) { return MUSC_ABI_VERSION; }
+
+const char* musc_last_error(musc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int musc_init(int device_ordinal, musc_ctx** out) {
+  if (!out) return fail(nullptr, 2, "musc_init: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, 3, "musc_init: no HIP device (%s); this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_ordinal < 0 || device_ordinal >= ndev)
+    return fail(nullptr, 2, "musc_init: device %d outside 0..%d", device_ordinal, ndev - 1);
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess)
+    return fail(nullptr, 3, "musc_init: hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, 3, "musc_init: device %d is %s; this library is built for gfx950 only",
+                device_ordinal, prop.gcnArchName);
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess)
+    return fail(nullptr, 3, "musc_init: hipSetDevice: %s", hipGetErrorString(e));
+  musc_ctx* c = new musc_ctx();
+  c->device = device_ordinal;
+  memset(&c->stats, 0, sizeof c->stats);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc((void**)&c->counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_pinned, 8 * sizeof(uint64_t))) != hipSuccess) {
+    fail(nullptr, 3, "musc_init: %s", hipGetErrorString(e));
+    musc_destroy(c);
+    return 3;
+  }
+  *out = c;
+  return 0;
+}
+
+void musc_destroy(musc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_db(c);
+  free_reads(c);
+  c->wstart.release(); c->wcnt.release(); c->rtot.release(); c->rbase.release(); c->scan_tmp.release();
+  c->p_read.release(); c->p_gpos.release(); c->p_meta.release(); c->p_gene.release(); c->p_nx.release();
+  c->nmiss_tab.release();
+  c->hits.release();
+  if (c->counters) (void)hipFree(c->counters);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ---------------------------------------------------------------- database
+
+static int db_finish(musc_ctx* c, uint32_t* d_hasx) {
+  uint32_t hasx = 0;
+  HIPCHK(c, hipMemcpyAsync(&hasx, d_hasx, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_hasx);
+  if (!hasx) {
+    (void)hipFree(c->dbm2);
+    c->dbm2 = nullptr;
+  }
+  return 0;
+}
+
+static int db_alloc(musc_ctx* c, const uint64_t* offsets, uint32_t nseq, int on_device, uint32_t** d_hasx) {
+  HIPCHK(c, hipSetDevice(c->device));
+  free_db(c);
+  if (nseq == 0) return fail(c, 2, "database has no sequences");
+  uint64_t first = 0, last = 0;
+  if (on_device) {
+    HIPCHK(c, hipMemcpy(&first, offsets, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&last, offsets + nseq, 8, hipMemcpyDeviceToHost));
+  } else {
+    first = offsets[0];
+    last = offsets[nseq];
+  }
+  if (first != 0) return fail(c, 2, "offsets[0] must be 0");
+  if (last >= (1ull << 40)) return fail(c, 2, "database larger than 2^40 bases");
+  c->nseq = nseq;
+  c->nbases = last;
+  c->db_words = (last + 15) / 16;
+  const uint64_t alloc_words = c->db_words + 64;  // slack: k_confirm reads a whole span past the last base
+  HIPCHK(c, hipMalloc((void**)&c->db2, alloc_words * 4));
+  HIPCHK(c, hipMalloc((void**)&c->dbm2, alloc_words * 4));
+  HIPCHK(c, hipMemsetAsync(c->db2, 0, alloc_words * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dbm2, 0, alloc_words * 4, c->stream));
+  HIPCHK(c, hipMalloc((void**)&c->seq_off, ((uint64_t)nseq + 1) * 8));
+  HIPCHK(c, hipMemcpyAsync(c->seq_off, offsets, ((uint64_t)nseq + 1) * 8,
+                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMalloc((void**)d_hasx, 4));
+  HIPCHK(c, hipMemsetAsync(*d_hasx, 0, 4, c->stream));
+  return 0;
+}
+
+int musc_db_load_ascii(musc_ctx* c, const char* seqs, const uint64_t* offsets, uint32_t nseq, int on_device) {
+  if (!c) return 1;
+  if (!seqs || !offsets) return fail(c, 2, "musc_db_load_ascii: NULL input");
+  uint32_t* d_hasx = nullptr;
+  int rc = db_alloc(c, offsets, nseq, on_device, &d_hasx);
+  if (rc) return rc;
+  const unsigned char* src = (const unsigned char*)seqs;
+  unsigned char* tmp = nullptr;
+  if (!on_device && c->nbases) {
+    HIPCHK(c, hipMalloc((void**)&tmp, c->nbases));
+    HIPCHK(c, hipMemcpyAsync(tmp, seqs, c->nbases, hipMemcpyHostToDevice, c->stream));
+    src = tmp;
+  }
+  if (c->db_words) {
+    hipLaunchKernelGGL(k_pack_db_ascii, dim3(nblk(c->db_words, 256)), dim3(256), 0, c->stream, src, c->nbases,
+                       c->db2, c->dbm2, c->db_words, d_hasx);
+    HIPCHK(c, hipGetLastError());
+  }
+  rc = db_finish(c, d_hasx);
+  if (tmp) (void)hipFree(tmp);
+  return rc;
+}
+
+int musc_db_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t* nmask, const uint64_t* seq_offsets,
+                        uint32_t nseq) {
+  if (!c) return 1;
+  if (!bases2bit || !seq_offsets) return fail(c, 2, "musc_db_load_packed: NULL input");
+  uint32_t* d_hasx = nullptr;
+  int rc = db_alloc(c, seq_offsets, nseq, 0, &d_hasx);
+  if (rc) return rc;
+  uint32_t* t2 = nullptr;
+  uint16_t* tm = nullptr;
+  const uint64_t w = c->db_words;
+  if (w) {
+    HIPCHK(c, hipMalloc((void**)&t2, w * 4));
+    HIPCHK(c, hipMemsetAsync(t2, 0, w * 4, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t2, bases2bit, (c->nbases + 3) / 4, hipMemcpyHostToDevice, c->stream));
+    if (nmask) {
+      HIPCHK(c, hipMalloc((void**)&tm, w * 2));
+      HIPCHK(c, hipMemsetAsync(tm, 0, w * 2, c->stream));
+      HIPCHK(c, hipMemcpyAsync(tm, nmask, (c->nbases + 7) / 8, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_pack_db_packed, dim3(nblk(w, 256)), dim3(256), 0, c->stream, t2, tm, c->db2, c->dbm2, w,
+                       d_hasx);
+    HIPCHK(c, hipGetLastError());
+  }
+  rc = db_finish(c, d_hasx);
+  if (t2) (void)hipFree(t2);
+  if (tm) (void)hipFree(tm);
+  return rc;
+}
+
+int musc_db_build_index(musc_ctx* c, int32_t ww) {
+  if (!c) return 1;
+  if (!c->db2) return fail(c, 4, "no database loaded");
+  if (ww < 1 || ww > 4096) return fail(c, 2, "bad window width %d", ww);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->idx_ww == ww && c->idx_A) return 0;
+  free_index(c);
+  // number of indexed window starts is at most nbases
+  if (c->nbases >= 0xFFFFFFF0ull)
+    return fail(c, 5, "database of %llu bases exceeds the 32-bit index offsets of this build",
+                (unsigned long long)c->nbases);
+  // Direct addressing (bucket = the 2*ww-bit key itself, exact) when the table is small or
+  // not much sparser than the database; otherwise a hashed table of >= 4 buckets per base.
+  int bits, direct = 0;
+  if (2 * ww <= 32 && ((1ull << (2 * ww)) <= (1ull << 24) || (1ull << (2 * ww)) <= 64 * c->nbases)) {
+    bits = 2 * ww;
+    direct = 1;
+  } else {
+    bits = 20;
+    while (bits < 32 && (1ull << bits) < 4 * c->nbases) bits++;
+  }
+  const uint64_t nb = 1ull << bits;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  HIPCHK(c, hipMalloc((void**)&c->idx_A, (nb + 2 + 64) * 4));
+  HIPCHK(c, hipMemsetAsync(c->idx_A, 0, (nb + 2 + 64) * 4, c->stream));
+  const unsigned blocks = nblk(c->nbases, 256);
+  if (c->nbases) {
+    hipLaunchKernelGGL(k_index<false>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
+                       c->nbases, ww, bits, direct, c->idx_A, (uint2*)nullptr);
+    HIPCHK(c, hipGetLastError());
+  }
+  int rc = ensure(c, c->scan_tmp, scan_tmp_elems(nb + 2));
+  if (rc) return rc;
+  rc = scan_u32(c, c->idx_A, c->idx_A, nb + 2, true, c->scan_tmp.p);
+  if (rc) return rc;
+  uint32_t total = 0;
+  HIPCHK(c, hipMemcpyAsync(&total, c->idx_A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->idx_n = total;
+  HIPCHK(c, hipMalloc((void**)&c->idx_entries, ((uint64_t)total + 16) * sizeof(uint2)));
+  if (c->nbases) {
+    hipLaunchKernelGGL(k_index<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
+                       c->nbases, ww, bits, direct, c->idx_A, c->idx_entries);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  c->stats.ms_index_build = ms;
+  c->idx_ww = ww;
+  c->idx_bits = bits;
+  c->idx_direct = direct;
+  return 0;
+}
+
+// ---------------------------------------------------------------- reads
+
+static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* bases2bit, const uint8_t* nmask,
+                      const uint64_t* offsets, uint64_t nreads, int on_device, bool packed) {
+  HIPCHK(c, hipSetDevice(c->device));
+  free_reads(c);
+  if (nreads >= 0xFFFFFFF0ull) return fail(c, 2, "too many reads for 32-bit read_idx");
+  c->nreads = nreads;
+  if (nreads == 0) {
+    c->rw = 4;
+    return 0;
+  }
+  uint64_t* d_off = nullptr;
+  const uint64_t* offp = offsets;
+  if (!on_device) {
+    HIPCHK(c, hipMalloc((void**)&d_off, (nreads + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(d_off, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    offp = d_off;
+  }
+  HIPCHK(c, hipMemsetAsync(c->counters + 4, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_max_len, dim3(nblk(nreads, 256)), dim3(256), 0, c->stream, offp, nreads, c->counters + 4);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters + 4, 8, hipMemcpyDeviceToHost, c->stream));
+  uint64_t first = 0, total = 0;
+  HIPCHK(c, hipMemcpyAsync(&first, offp, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&total, offp + nreads, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint64_t maxlen = c->h_pinned[0];
+  if (first != 0) return fail(c, 2, "read offsets[0] must be 0");
+  if (maxlen > 65535) return fail(c, 2, "read of %llu bases exceeds the 65535-base record limit", (unsigned long long)maxlen);
+  c->max_len = (uint32_t)maxlen;
+  int rw = (int)((2 * maxlen + 31) / 32) + 1;
+  rw = (rw + 3) & ~3;
+  if (rw < 4) rw = 4;
+  c->rw = rw;
+  const uint64_t words = nreads * (uint64_t)rw;
+  HIPCHK(c, hipMalloc((void**)&c->rd, words * 4 + 256));
+  HIPCHK(c, hipMalloc((void**)&c->rdm, words * 4 + 256));
+  HIPCHK(c, hipMemsetAsync(c->rd + words, 0, 256, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->rdm + words, 0, 256, c->stream));
+  uint32_t* d_hasx = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_hasx, 4));
+  HIPCHK(c, hipMemsetAsync(d_hasx, 0, 4, c->stream));
+  void *t1 = nullptr, *t2 = nullptr;
+  if (words / 256 + 1 > 0x7FFFFFFFull) return fail(c, 2, "too many read words");
+  if (!packed) {
+    const unsigned char* src = ascii;
+    if (!on_device && total) {
+      HIPCHK(c, hipMalloc(&t1, total));
+      HIPCHK(c, hipMemcpyAsync(t1, ascii, total, hipMemcpyHostToDevice, c->stream));
+      src = (const unsigned char*)t1;
+    }
+    hipLaunchKernelGGL(k_pack_reads<false>, dim3(nblk(words, 256)), dim3(256), 0, c->stream, src,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, offp, nreads, rw, c->rd, c->rdm, d_hasx);
+  } else {
+    const uint64_t b2 = ((total + 3) / 4 + 7) & ~3ull, bm = ((total + 7) / 8 + 7) & ~3ull;
+    HIPCHK(c, hipMalloc(&t1, b2 + 16));
+    HIPCHK(c, hipMemsetAsync(t1, 0, b2 + 16, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t1, bases2bit, (total + 3) / 4, hipMemcpyHostToDevice, c->stream));
+    if (nmask) {
+      HIPCHK(c, hipMalloc(&t2, bm + 16));
+      HIPCHK(c, hipMemsetAsync(t2, 0, bm + 16, c->stream));
+      HIPCHK(c, hipMemcpyAsync(t2, nmask, (total + 7) / 8, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_pack_reads<true>, dim3(nblk(words, 256)), dim3(256), 0, c->stream,
+                       (const unsigned char*)nullptr, (const uint32_t*)t1, (const uint32_t*)t2, offp, nreads, rw,
+                       c->rd, c->rdm, d_hasx);
+  }
+  HIPCHK(c, hipGetLastError());
+  uint32_t hasx = 0;
+  HIPCHK(c, hipMemcpyAsync(&hasx, d_hasx, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_hasx);
+  if (t1) (void)hipFree(t1);
+  if (t2) (void)hipFree(t2);
+  if (d_off) (void)hipFree(d_off);
+  if (!hasx) {
+    (void)hipFree(c->rdm);
+    c->rdm = nullptr;
+  }
+  return 0;
+}
+
+int musc_reads_load_ascii(musc_ctx* c, const char* seqs, const uint64_t* offsets, uint64_t nreads, int on_device) {
+  if (!c) return 1;
+  if ((!seqs || !offsets) && nreads) return fail(c, 2, "musc_reads_load_ascii: NULL input");
+  return reads_load(c, (const unsigned char*)seqs, nullptr, nullptr, offsets, nreads, on_device, false);
+}
+
+int musc_reads_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t* nmask, const uint64_t* read_offsets,
+                           uint64_t nreads) {
+  if (!c) return 1;
+  if ((!bases2bit || !read_offsets) && nreads) return fail(c, 2, "musc_reads_load_packed: NULL input");
+  return reads_load(c, nullptr, bases2bit, nmask, read_offsets, nreads, 0, true);
+}
+
+// ---------------------------------------------------------------- hot path
+
+int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
+  if (!c) return 1;
+  int rc = check_params(c, P);
+  if (rc) return rc;
+  if (!c->db2) return fail(c, 4, "no database loaded");
+  if (!c->rd && c->nreads) return fail(c, 4, "no reads loaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  rc = musc_db_build_index(c, P->window_width);
+  if (rc) return rc;
+
+  const float keep_index_ms = c->stats.ms_index_build;
+  memset(&c->stats, 0, sizeof c->stats);
+  c->stats.ms_index_build = keep_index_ms;
+  c->stats.n_reads = c->nreads;
+  c->nhits = 0;
+  if (nhits) *nhits = 0;
+
+  PathParams pp;
+  memset(&pp, 0, sizeof pp);
+  pp.W = P->n_windows;
+  pp.ww = P->window_width;
+  pp.min_dinuc = P->min_dinuc;
+  pp.bits = c->idx_bits;
+  pp.direct = c->idx_direct;
+  pp.mmtol = P->mmtol > 0xFFFF ? 0xFFFF : P->mmtol;
+  pp.apply_mmtol = P->apply_mmtol;
+  for (int k = 0; k < pp.W; k++) {
+    pp.win[k] = P->windows[k];
+    if (P->windows[k] == 0) pp.q1zero_mask |= 1u << k;
+  }
+
+  // nmiss budget per read length: int((1-PMatch)*float64(len)), IEEE double, truncation
+  // (cmd/muscato_confirm/main.go:198) -- evaluated on the host exactly as Go does.
+  {
+    std::vector<uint16_t> tab((size_t)c->max_len + 2);
+    for (uint32_t L = 0; L < tab.size(); L++) {
+      volatile double a = 1.0 - P->pmatch;
+      volatile double b = a * (double)L;
+      long long v = (long long)b;
+      if (v < 0) v = 0;
+      if (v > 0xFFFE) v = 0xFFFE;
+      tab[L] = (uint16_t)v;
+    }
+    rc = ensure(c, c->nmiss_tab, tab.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->nmiss_tab.p, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // tab goes out of scope
+  }
+
+  HIPCHK(c, hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  Timer tm(c);
+  hipEvent_t ev0, ev1;
+  HIPCHK(c, hipEventCreate(&ev0));
+  HIPCHK(c, hipEventCreate(&ev1));
+  HIPCHK(c, hipEventRecord(ev0, c->stream));
+
+  const bool mask = c->rdm || c->dbm2;
+  // a mask plane on only one side: allocate the missing all-zero plane once
+  if (mask && !c->rdm && c->nreads) {
+    const uint64_t words = c->nreads * (uint64_t)c->rw;
+    HIPCHK(c, hipMalloc((void**)&c->rdm, words * 4 + 256));
+    HIPCHK(c, hipMemsetAsync(c->rdm, 0, words * 4 + 256, c->stream));
+  }
+  if (mask && !c->dbm2) {
+    HIPCHK(c, hipMalloc((void**)&c->dbm2, (c->db_words + 64) * 4));
+    // (the index stays valid: bucket_of treats a null and an all-zero mask plane alike)
+    HIPCHK(c, hipMemsetAsync(c->dbm2, 0, (c->db_words + 64) * 4, c->stream));
+  }
+
+  const uint64_t PAIR_CAP = 1ull << 30;  // pairs per batch (19 B of work buffers each)
+  uint64_t r0 = 0;
+  uint32_t bsz = c->batch_reads;
+  while (r0 < c->nreads) {
+    const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
+    const int W = pp.W;
+    if ((rc = ensure(c, c->wstart, (uint64_t)n * W))) return rc;
+    if ((rc = ensure(c, c->wcnt, (uint64_t)n * W))) return rc;
+    if ((rc = ensure(c, c->rtot, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->rbase, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)n + 1)))) return rc;
+
+    tm.begin(0);
+    HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->rtot.p + n, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_seed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp,
+                       c->idx_A, c->wstart.p, c->wcnt.p, c->rtot.p, c->counters);
+    HIPCHK(c, hipGetLastError());
+    tm.end(0);
+    tm.begin(1);
+    rc = scan_u32(c, c->rtot.p, c->rbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
+    if (rc) return rc;
+    tm.end(1);
+    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 3, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[1], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t total = c->h_pinned[0];
+    const uint64_t hits_so_far = c->h_pinned[1];
+    if (total > PAIR_CAP) {
+      // too many candidate pairs for one launch: retry this range with half the reads
+      if (n == 1) return fail(c, 6, "one read has %llu candidate pairs (> 2^30)", (unsigned long long)total);
+      bsz = n / 2;
+      continue;
+    }
+    c->stats.n_batches++;
+    {
+      if ((rc = ensure(c, c->p_read, total))) return rc;
+      if ((rc = ensure(c, c->p_gpos, total))) return rc;
+      if ((rc = ensure(c, c->p_meta, total))) return rc;
+      if ((rc = ensure(c, c->p_gene, total))) return rc;
+      if ((rc = ensure(c, c->p_nx, total))) return rc;
+      if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
+
+      tm.begin(2);
+      hipLaunchKernelGGL(k_expand, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->rd, r0, n, c->rw, pp,
+                         c->wstart.p, c->wcnt.p, c->rbase.p, c->idx_entries, c->seq_off, c->p_read.p, c->p_gpos.p,
+                         c->p_meta.p, c->p_gene.p, c->counters);
+      HIPCHK(c, hipGetLastError());
+      tm.end(2);
+
+      if (total) {
+      tm.begin(3);
+      switch (c->rw) {
+        case 4: launch_confirm<4>(c, mask, r0, pp, total); break;
+        case 8: launch_confirm<8>(c, mask, r0, pp, total); break;
+        case 12: launch_confirm<12>(c, mask, r0, pp, total); break;
+        case 16: launch_confirm<16>(c, mask, r0, pp, total); break;
+        default: launch_confirm<0>(c, mask, r0, pp, total); break;
+      }
+      HIPCHK(c, hipGetLastError());
+      tm.end(3);
+      c->stats.confirm_launches++;
+      c->stats.n_pairs += total;
+      }
+
+      tm.begin(4);
+      hipLaunchKernelGGL(k_select, dim3(nblk(n, 256)), dim3(256), 0, c->stream, r0, n, pp, c->rbase.p, c->p_gpos.p,
+                         c->p_meta.p, c->p_gene.p, c->p_nx.p, c->seq_off, c->hits.p, c->counters);
+      HIPCHK(c, hipGetLastError());
+      tm.end(4);
+    }
+    r0 += n;
+  }
+  HIPCHK(c, hipEventRecord(ev1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 3 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stats.n_read_windows = c->h_pinned[0];
+  c->stats.n_accepted = c->h_pinned[1];
+  c->stats.n_hits = c->nhits = c->h_pinned[2];
+  c->stats.ms_seed = tm.total(0);
+  c->stats.ms_scan = tm.total(1);
+  c->stats.ms_expand = tm.total(2);
+  c->stats.ms_confirm = tm.total(3);
+  c->stats.ms_select = tm.total(4);
+  (void)hipEventElapsedTime(&c->stats.ms_total, ev0, ev1);
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  // 12 B descriptor + ceil(2L/8) B read + ceil(2L/8)+1 B target span per pair
+  const uint64_t L = c->max_len;
+  c->stats.confirm_bytes = c->stats.n_pairs * (12 + (2 * L + 7) / 8 + (2 * L + 7) / 8 + 1);
+  if (nhits) *nhits = c->nhits;
+  return 0;
+}
+
+int musc_hits_copy(musc_ctx* c, musc_hit* dst, uint64_t capacity, int dst_on_device) {
+  if (!c) return 1;
+  if (capacity < c->nhits) return fail(c, 2, "musc_hits_copy: capacity %llu < %llu hits",
+                                       (unsigned long long)capacity, (unsigned long long)c->nhits);
+  if (c->nhits == 0) return 0;
+  if (!dst) return fail(c, 2, "musc_hits_copy: dst is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(dst, c->hits.p, c->nhits * sizeof(musc_hit),
+                           dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int musc_match(musc_ctx* c, const musc_params* P, musc_hit** hits, uint64_t* nhits) {
+  if (!c) return 1;
+  if (!hits || !nhits) return fail(c, 2, "musc_match: NULL output pointer");
+  *hits = nullptr;
+  *nhits = 0;
+  uint64_t n = 0;
+  int rc = musc_match_device(c, P, &n);
+  if (rc) return rc;
+  musc_hit* h = (musc_hit*)malloc(sizeof(musc_hit) * (n ? n : 1));
+  if (!h) return fail(c, 7, "out of host memory for %llu hits", (unsigned long long)n);
+  rc = musc_hits_copy(c, h, n, 0);
+  if (rc) {
+    free(h);
+    return rc;
+  }
+  *hits = h;
+  *nhits = n;
+  return 0;
+}
+
+void musc_free_hits(musc_hit* hits) { free(hits); }
+
+int musc_get_stats(musc_ctx* c, musc_stats* out) {
+  if (!c || !out) return 1;
+  *out = c->stats;
+  return 0;
+}
+
+int musc_gather(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hit** hits, uint64_t* nhits) {
+  if (!ctxs || n < 1 || !hits || !nhits) return 1;
+  uint64_t total = 0;
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i]) return 1;
+    total += ctxs[i]->nhits;
+  }
+  musc_hit* h = (musc_hit*)malloc(sizeof(musc_hit) * (total ? total : 1));
+  if (!h) return fail(ctxs[0], 7, "musc_gather: out of host memory");
+  uint64_t o = 0;
+  for (int i = 0; i < n; i++) {
+    musc_ctx* c = ctxs[i];
+    int rc = musc_hits_copy(c, h + o, c->nhits, 0);
+    if (rc) {
+      free(h);
+      return rc;
+    }
+    const uint64_t base = read_base ? read_base[i] : 0;
+    for (uint64_t j = 0; j < c->nhits; j++) h[o + j].read_idx += (uint32_t)base;
+    o += c->nhits;
+  }
+  *hits = h;
+  *nhits = total;
+  return 0;
+}
+
+}  // extern "C"

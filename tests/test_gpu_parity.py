@@ -1,0 +1,217 @@
+"""GPU parity tests: the HIP hot path (through the C ABI) against the CPU oracle.
+
+Bit-exact bar: the set of (read, gene, pos, nmiss) tuples must be identical.
+Run on the GPU box with ``pytest -m gpu``; everything here goes through
+libmuscato_hip.so -- there is no CPU fallback to fall into.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import literal
+from oracle import muscato_oracle as orc
+
+from cases import make_case, mutate, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from muscato_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def to_cfg(ocfg):
+    from muscato_amd import Config
+    return Config(Windows=list(ocfg.Windows), WindowWidth=ocfg.WindowWidth, PMatch=ocfg.PMatch,
+                  MinDinuc=ocfg.MinDinuc, MaxReadLength=ocfg.MaxReadLength, MaxMatches=ocfg.MaxMatches,
+                  MMTol=ocfg.MMTol, MatchMode=ocfg.MatchMode)
+
+
+def as_arr(hits):
+    return np.array(sorted(hits), dtype=np.uint32).reshape(-1, 4)
+
+
+def gpu_hits(eng, ocfg, reads, targets, apply_mmtol):
+    from muscato_amd import sorted_hits
+    eng.load_targets(targets)
+    eng.load_reads(reads)
+    return sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=apply_mmtol))
+
+
+def assert_same(got, exp):
+    assert got.shape == exp.shape, "hit count differs: gpu %d vs oracle %d" % (len(got), len(exp))
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_cases_match_oracle(eng, seed):
+    """Same seeded cases as tests/test_oracle_cross.py (X bases, ragged lengths, pos-0,
+    target-end, 1-3 windows, PMatch 0.7-1, MinDinuc 0-5)."""
+    ocfg, reads, targets = make_case(seed)
+    full = orc.match_direct(reads, targets, ocfg)
+    assert_same(gpu_hits(eng, ocfg, reads, targets, False), as_arr(full))
+    from muscato_amd import sorted_hits
+    got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=True))
+    assert_same(got, as_arr(orc.best_filter(full, ocfg.MMTol)))
+
+
+MUSCATO_CASES = [("00", False), ("01", False), ("02", False), ("03", False), ("04", True)]
+
+
+@pytest.mark.parametrize("case,rev", MUSCATO_CASES)
+def test_reference_fixture_results(eng, golden_dir, case, rev):
+    """The reference's own end-to-end fixtures (tests/tests.toml:70-139): hot path on the GPU,
+    text prep/post around it, byte-identical results.txt and nonmatch fastq."""
+    d = os.path.join(golden_dir, "muscato", case)
+    with open(os.path.join(d, "config.json"), "rb") as f:
+        ocfg = orc.Config.from_json(json.loads(f.read()))
+    seqs, ids = orc.prep_targets_file(os.path.join(d, "genes.txt"), rev)
+    with open(os.path.join(d, "reads.fastq"), "rb") as f:
+        ureads = orc.uniqify(orc.prep_reads(orc.read_fastq(f.read()), ocfg))
+    reads = [u.seq for u in ureads]
+    got = gpu_hits(eng, ocfg, reads, seqs, True)
+    hits = [tuple(int(x) for x in row) for row in got]
+    res = orc.results_text(hits, ureads, seqs, ids, ocfg)
+    with open(os.path.join(d, "result_e.txt"), "rb") as f:
+        assert res == f.read()
+    with open(os.path.join(d, "result.nonmatch_e.txt"), "rb") as f:
+        assert orc.nonmatch_text(res, ureads) == f.read()
+
+
+def test_packed_loaders_equal_ascii_loaders(eng):
+    from muscato_amd import sorted_hits
+    for seed in (0, 3, 7, 9):  # seeds 0, 3, 9 use the X alphabet
+        ocfg, reads, targets = make_case(seed)
+        exp = gpu_hits(eng, ocfg, reads, targets, False)
+        eng.load_targets_packed(targets)
+        eng.load_reads_packed(reads)
+        got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+        assert_same(got, exp)
+
+
+def test_literal_100_rule_on_gpu(eng):
+    rng = random.Random(5)
+    t = rand_seq(rng, 300, b"ACGT")
+    c1 = orc.Config(Windows=[0], WindowWidth=15, PMatch=1.0, MaxReadLength=100)
+    c2 = orc.Config(Windows=[0, 20], WindowWidth=15, PMatch=1.0, MaxReadLength=100)
+    assert len(gpu_hits(eng, c1, [t[:86]], [t], False)) == 0
+    assert_same(gpu_hits(eng, c1, [t[:85]], [t], False), as_arr([(0, 0, 0, 0)]))
+    assert_same(gpu_hits(eng, c2, [t[:100]], [t], False), as_arr([(0, 0, 0, 0)]))
+    assert_same(gpu_hits(eng, c1, [t[1:101]], [t], False), as_arr([(0, 0, 1, 0)]))
+
+
+def test_x_semantics_on_gpu(eng):
+    t = b"ACGTACGTXXACGTTTGACA"
+    c = orc.Config(Windows=[0], WindowWidth=4, PMatch=0.8, MaxReadLength=50)
+    reads = [b"ACGTACGTXXAC", b"ACGTACGTAXAC", b"ACGTXCGTXXAC"]
+    assert_same(gpu_hits(eng, c, reads, [t], False), as_arr([(0, 0, 0, 0), (1, 0, 0, 1), (2, 0, 0, 1)]))
+    # a window made of X only matches X at the same places
+    c = orc.Config(Windows=[0], WindowWidth=4, PMatch=1.0, MaxReadLength=50)
+    reads = [b"AXXAGG", b"AAAAGG"]
+    targets = [b"TTAXXAGGTT", b"TTAAAAGGTT"]
+    assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
+    assert_same(gpu_hits(eng, c, reads, targets, False), as_arr([(0, 0, 2, 0), (1, 1, 2, 0)]))
+
+
+def test_empty_and_degenerate_inputs(eng):
+    c = orc.Config(Windows=[0, 5], WindowWidth=4, PMatch=1.0, MaxReadLength=50)
+    targets = [b"ACGTACGTACGTTTGACA", b"", b"ACG", b"GGGGGGGGGGGG"]
+    # no reads at all
+    assert len(gpu_hits(eng, c, [], targets, False)) == 0
+    # reads shorter than every window; a read that matches nothing
+    assert len(gpu_hits(eng, c, [b"ACG", b"A"], targets, True)) == 0
+    assert len(gpu_hits(eng, c, [b"TTTTTTTTTT"], targets, True)) == 0
+    # empty and too-short targets in the middle keep gene numbering intact
+    reads = [b"GGGGGGGG", b"ACGTACGTA"]
+    assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
+
+
+@pytest.mark.parametrize("maxlen", [31, 48, 100, 112, 113, 150, 200, 250, 400])
+def test_read_length_strides(eng, maxlen):
+    """Record strides 4/8/12/16 words (compiled) and the runtime-stride kernel."""
+    rng = random.Random(maxlen)
+    targets = [rand_seq(rng, rng.randint(maxlen, 3 * maxlen), b"ACGT") for _ in range(12)]
+    targets += [mutate(rng, t, 0.02, b"ACGT") for t in targets[:5]]
+    reads = set()
+    for _ in range(60):
+        t = rng.choice(targets)
+        L = rng.randint(max(20, maxlen // 2), maxlen)
+        p = rng.choice([0, len(t) - L, rng.randint(0, len(t) - L)])
+        reads.add(mutate(rng, t[p:p + L], rng.choice([0, 0.02, 0.05]), b"ACGT"))
+    reads.add(rand_seq(rng, maxlen, b"ACGT"))
+    reads = sorted(reads)
+    c = orc.Config(Windows=[0, 11], WindowWidth=10, PMatch=0.9, MinDinuc=3, MaxReadLength=maxlen, MMTol=2)
+    assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
+
+
+def test_wide_windows(eng):
+    """WindowWidth > 16 uses the hashed index; > 32 folds several key words."""
+    rng = random.Random(77)
+    targets = [rand_seq(rng, 400, b"ACGT") for _ in range(10)]
+    reads = sorted({mutate(rng, t[p:p + 120], 0.01, b"ACGT") for t in targets for p in (0, 37, 280)})
+    for ww in (17, 20, 31, 32, 33, 40, 64):
+        c = orc.Config(Windows=[0, 45], WindowWidth=ww, PMatch=0.95, MaxReadLength=120)
+        assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
+
+
+def synthetic_medium(seed, n_targets, n_reads, tlen=1000, L=100, xrate=0.0):
+    rng = np.random.default_rng(seed)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    T = bases[rng.integers(0, 4, size=(n_targets, tlen))]
+    ncopy = n_targets // 5
+    src = rng.integers(0, n_targets - ncopy, size=ncopy)
+    T[n_targets - ncopy:] = T[src]
+    sub = rng.random((ncopy, tlen)) < 0.02
+    T[n_targets - ncopy:][sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    if xrate:
+        T[rng.random(T.shape) < xrate] = ord("X")
+    g = rng.integers(0, n_targets, size=n_reads)
+    p = rng.integers(0, tlen - L + 1, size=n_reads)
+    p[rng.random(n_reads) < 0.01] = 0
+    p[rng.random(n_reads) < 0.01] = tlen - L
+    R = T[g[:, None], p[:, None] + np.arange(L)[None, :]].copy()
+    sub = rng.random(R.shape) < 0.01
+    R[sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    nrand = n_reads // 5
+    R[:nrand] = bases[rng.integers(0, 4, size=(nrand, L))]
+    if xrate:
+        R[rng.random(R.shape) < xrate] = ord("X")
+    reads = sorted({bytes(r) for r in R})
+    targets = [bytes(t) for t in T]
+    return reads, targets
+
+
+@pytest.mark.parametrize("xrate", [0.0, 0.001])
+def test_medium_synthetic_against_literal_oracle(eng, xrate):
+    """20k reads x 2k targets of 1000 bp, the BASELINE config-2 parameters, against the
+    reference-shaped C++ oracle (Bloom + rolling hash screen, sorted merge-join confirm)."""
+    reads, targets = synthetic_medium(11, 2000, 20000, xrate=xrate)
+    c = orc.Config(Windows=[0, 20], WindowWidth=15, PMatch=0.97, MinDinuc=5, MaxReadLength=100,
+                   MaxMatches=1000000, MMTol=0)
+    rbuf, roff = literal.concat(reads)
+    gbuf, goff = literal.concat(targets)
+    exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff,
+                                     literal.make_params(c, bloom_size=64_000_000, num_hash=8, nthreads=8))
+    got = gpu_hits(eng, c, reads, targets, False)
+    assert len(got) > 10000
+    assert_same(got, exp)
+    st = eng.stats()
+    assert st["n_pairs"] >= st["n_accepted"] >= len(got) > 0
+    assert st["n_reads"] == len(reads)
+
+
+def test_stats_and_repeat_calls_are_stable(eng):
+    from muscato_amd import sorted_hits
+    ocfg, reads, targets = make_case(4)
+    a = gpu_hits(eng, ocfg, reads, targets, False)
+    b = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+    assert_same(a, b)
+    st = eng.stats()
+    assert st["n_hits"] == len(a) and st["ms_total"] >= 0
