@@ -1,0 +1,131 @@
+"""Synthetic workloads of SURVEY.md 8(d) / BASELINE.json, generated with torch on the device
+that will run them (torch is plumbing here: device memory + RNG, nothing else).
+
+Targets: iid uniform ACGT; ``copy_frac`` of them are copies of a random earlier target with
+``copy_sub`` iid substitutions (non-trivial multi-map).
+Raw reads, R in total: 70 % sampled from a uniformly random target at a uniform offset
+(offset 0 forced for 0.1 % -> the pos-0 path) with 1 %/base iid substitutions; 20 % iid random
+(non-matching); 10 % exact duplicates of an earlier read.  The reference de-duplicates before
+its hot path (cmd/muscato_uniqify), so the duplicates are dropped by construction: the hot
+path sees U = R - R/10 unique reads and reads/sec is quoted on R.
+
+The Go reference's generator (cmd/muscato_gendat/main.go:99-136, unseeded math/rand) cannot be
+reproduced bit for bit; ``gendat_like`` mirrors its structure (random reads; gene i < G/2
+carries read i%10 at offset i%10) for a tests/bigtest/test.sh-shaped smoke run.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+SEED_BASE = 0x4D555343  # "MUSC"
+
+
+@dataclass
+class Workload:
+    name: str
+    n_targets: int
+    target_len: int
+    n_raw_reads: int
+    read_len: int
+    windows: tuple
+    window_width: int
+    pmatch: float
+    mmtol: int
+    min_dinuc: int
+    max_matches: int = 1000 * 1000
+    match_mode: str = "best"
+
+    @property
+    def n_unique_reads(self) -> int:
+        return self.n_raw_reads - self.n_raw_reads // 10
+
+
+# BASELINE.json "configs" (SURVEY.md 8d): cfg2 = configs[1], cfg3 = configs[2], ...
+WORKLOADS = {
+    "cfg2": Workload("cfg2: 1M reads x 100k targets", 100_000, 1000, 1_000_000, 100, (0, 20), 15, 0.97, 0, 5),
+    "cfg3": Workload("cfg3: 50M reads x 1M targets", 1_000_000, 1000, 50_000_000, 100, (0, 20), 15, 0.97, 0, 5),
+    # per-GPU shard of cfg4 (200M reads / 8 GPUs) against the same replicated 1M-target DB
+    "cfg4shard": Workload("cfg4 shard: 25M reads x 1M targets", 1_000_000, 1000, 25_000_000, 100, (0, 20), 15,
+                          0.97, 0, 5),
+    "tiny": Workload("tiny: 20k reads x 2k targets", 2_000, 1000, 20_000, 100, (0, 20), 15, 0.97, 0, 5),
+}
+
+_ASCII = (65, 67, 71, 84)  # A C G T
+
+
+def _lut(device):
+    return torch.tensor(_ASCII, dtype=torch.uint8, device=device)
+
+
+def gen_targets(wl: Workload, device, seed: int, copy_frac: float = 0.2, copy_sub: float = 0.02,
+                chunk: int = 100_000) -> torch.Tensor:
+    """-> uint8 ASCII tensor [n_targets, target_len] on `device`."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    T, L = wl.n_targets, wl.target_len
+    out = torch.empty((T, L), dtype=torch.uint8, device=device)
+    for s in range(0, T, chunk):
+        e = min(T, s + chunk)
+        out[s:e] = torch.randint(0, 4, (e - s, L), dtype=torch.uint8, device=device, generator=g)
+    ncopy = int(T * copy_frac)
+    if ncopy and T - ncopy > 0:
+        for s in range(T - ncopy, T, chunk):
+            e = min(T, s + chunk)
+            src = torch.randint(0, T - ncopy, (e - s,), device=device, generator=g)
+            blk = out[src]
+            sub = torch.rand((e - s, L), device=device, generator=g) < copy_sub
+            rnd = torch.randint(0, 4, (e - s, L), dtype=torch.uint8, device=device, generator=g)
+            out[s:e] = torch.where(sub, rnd, blk)
+    lut = _lut(device)
+    for s in range(0, T, chunk):
+        e = min(T, s + chunk)
+        out[s:e] = lut[out[s:e].long()]
+    return out
+
+
+def gen_unique_reads(wl: Workload, targets_ascii: torch.Tensor, device, seed: int, n_unique: int = None,
+                     sub_rate: float = 0.01, chunk: int = 1_000_000) -> torch.Tensor:
+    """-> uint8 ASCII tensor [U, read_len]: the unique reads the hot path processes
+    (7/9 sampled from targets, 2/9 random), in random order."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    U = wl.n_unique_reads if n_unique is None else n_unique
+    L, TL, T = wl.read_len, wl.target_len, wl.n_targets
+    out = torch.empty((U, L), dtype=torch.uint8, device=device)
+    lut = _lut(device)
+    ar = torch.arange(L, device=device)
+    flat = targets_ascii.reshape(-1)
+    for s in range(0, U, chunk):
+        e = min(U, s + chunk)
+        n = e - s
+        gi = torch.randint(0, T, (n,), device=device, generator=g)
+        off = torch.randint(0, TL - L + 1, (n,), device=device, generator=g)
+        off = torch.where(torch.rand((n,), device=device, generator=g) < 0.001, torch.zeros_like(off), off)
+        base = gi * TL + off
+        blk = flat[(base[:, None] + ar[None, :])]
+        rnd = lut[torch.randint(0, 4, (n, L), device=device, generator=g).long()]
+        sub = torch.rand((n, L), device=device, generator=g) < sub_rate
+        israndom = torch.rand((n,), device=device, generator=g) < (2.0 / 9.0)
+        out[s:e] = torch.where(sub | israndom[:, None], rnd, blk)
+    return out
+
+
+def offsets_for(n: int, length: int, device) -> torch.Tensor:
+    """uint64 offsets [n+1] of fixed-length sequences, stored in an int64 tensor."""
+    return torch.arange(0, n + 1, dtype=torch.int64, device=device) * length
+
+
+def gendat_like(n_reads: int, n_genes: int, read_len: int, gene_len: int, device, seed: int):
+    """cmd/muscato_gendat/main.go:99-136 shape: random reads; gene i < G/2 carries read i%10
+    at offset i%10."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lut = _lut(device)
+    reads = lut[torch.randint(0, 4, (n_reads, read_len), device=device, generator=g).long()]
+    genes = lut[torch.randint(0, 4, (n_genes, gene_len), device=device, generator=g).long()]
+    h = n_genes // 2
+    for j in range(min(10, h)):
+        genes[j:h:10, j:j + read_len] = reads[j]
+    return reads, genes
