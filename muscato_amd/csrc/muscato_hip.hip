@@ -74,6 +74,24 @@ DEV uint32_t bucket_of(const uint32_t* __restrict__ w, const uint32_t* __restric
   return (uint32_t)(h >> (64 - bits));
 }
 
+// Sum `v` over the block and add it to *dst with ONE atomic (single-address atomics
+// serialise at ~90 M/s on MI355X, so per-wave atomics from a big grid cost milliseconds).
+DEV void block_add_u64(unsigned long long v, unsigned long long* dst) {
+  __shared__ unsigned long long s_acc[16];
+  for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+  const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) s_acc[wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < nw; w++) t += s_acc[w];
+    if (t) atomicAdd(dst, t);
+  }
+  __syncthreads();
+}
+
+#define MAX_GRID 4096u  // grid-stride kernels: enough blocks to fill 256 CUs several times
+
 // ------------------------------------------------------------------------------------
 // packing kernels (ASCII / 2-bit stream -> device layout)
 // ------------------------------------------------------------------------------------
@@ -123,14 +141,22 @@ __global__ void k_pack_db_packed(const uint32_t* __restrict__ in2, const uint16_
 }
 
 __global__ void k_max_len(const uint64_t* __restrict__ off, uint64_t n, unsigned long long* out) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ unsigned long long s_m[16];
   unsigned long long l = 0;
-  if (i < n) l = off[i + 1] - off[i];
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long v = off[i + 1] - off[i];
+    l = v > l ? v : l;
+  }
   for (int d = 32; d; d >>= 1) {
     const unsigned long long o = __shfl_xor(l, d);
     l = o > l ? o : l;
   }
-  if ((threadIdx.x & 63) == 0 && l) atomicMax(out, l);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (unsigned w = 1; w < (blockDim.x + 63) / 64; w++) l = s_m[w] > l ? s_m[w] : l;
+    if (l) atomicMax(out, l);
+  }
 }
 
 // one thread per (read, record word).  Record = rw u32 words: bases in words 0..rw-2
@@ -316,9 +342,8 @@ __global__ __launch_bounds__(256) void k_seed(uint32_t* __restrict__ rd,
                                               uint32_t* __restrict__ wcnt,
                                               uint32_t* __restrict__ rtot,
                                               unsigned long long* __restrict__ counters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t nvalid = 0;
-  if (i < n) {
+  unsigned long long t64 = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint64_t r = r0 + i;
     uint32_t* rec = rd + r * (uint64_t)rw;
     const uint32_t* recm = rdm ? rdm + r * (uint64_t)rw : nullptr;
@@ -342,12 +367,10 @@ __global__ __launch_bounds__(256) void k_seed(uint32_t* __restrict__ rd,
     }
     rec[rw - 1] = len | (valid << 16);
     rtot[i] = tot;
-    nvalid = tot;
+    t64 += tot;
   }
   // 64-bit total of candidate pairs of this launch (the u32 scan could wrap)
-  unsigned long long t64 = nvalid;
-  for (int d = 32; d; d >>= 1) t64 += __shfl_xor(t64, d);
-  if ((threadIdx.x & 63) == 0 && t64) atomicAdd(&counters[3], t64);
+  block_add_u64(t64, &counters[3]);
 }
 
 #define PAIR_INVALID 0xFFFFFFFFu
@@ -369,38 +392,38 @@ __global__ __launch_bounds__(256) void k_expand(const uint32_t* __restrict__ rd,
                                                 uint32_t* __restrict__ p_meta,
                                                 uint32_t* __restrict__ p_gene,
                                                 unsigned long long* __restrict__ counters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t nvalid = 0;
-  if (i < n) nvalid = __popc(rd[(r0 + i) * (uint64_t)rw + rw - 1] >> 16);
-  for (int d = 32; d; d >>= 1) nvalid += __shfl_xor(nvalid, d);
-  if ((threadIdx.x & 63) == 0 && nvalid) atomicAdd(&counters[0], (unsigned long long)nvalid);
-  if (i >= n) return;
-  const int64_t len = rd[(r0 + i) * (uint64_t)rw + rw - 1] & 0xFFFFu;
-  uint64_t out = rbase[i];
-  for (int k = 0; k < pp.W; k++) {
-    const uint32_t s = wstart[(uint64_t)i * pp.W + k];
-    const uint32_t c = wcnt[(uint64_t)i * pp.W + k];
-    const int64_t q1 = pp.win[k];
-    for (uint32_t e = 0; e < c; e++) {
-      const uint2 ent = entries[(uint64_t)s + e];
-      const uint64_t go = seq_off[ent.x];
-      const int64_t T = (int64_t)(seq_off[ent.x + 1] - go);
-      const int64_t jx = ent.y;
-      const int64_t p = jx - q1;
-      int64_t lim0 = 100 - pp.ww;  // cmd/muscato_screen/main.go:305 (q1 == 0 there)
-      if (lim0 > T) lim0 = T;
-      const bool fit0 = len <= lim0;
-      bool ok = p >= 0;
-      if (jx == 0) ok = ok && fit0; else ok = ok && (p + len <= T);
-      const uint32_t z = (p == 0 && !fit0) ? 1u : 0u;
-      const uint64_t gpos = go + (uint64_t)(p > 0 ? p : 0);
-      p_read[out] = ok ? i : PAIR_INVALID;
-      p_gpos[out] = (uint32_t)gpos;
-      p_meta[out] = (uint32_t)k | (z << 4) | ((uint32_t)(gpos >> 32) << 8);
-      p_gene[out] = ent.x;
-      out++;
+  unsigned long long nvalid = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t rmeta = rd[(r0 + i) * (uint64_t)rw + rw - 1];
+    nvalid += __popc(rmeta >> 16);
+    const int64_t len = rmeta & 0xFFFFu;
+    uint64_t out = rbase[i];
+    for (int k = 0; k < pp.W; k++) {
+      const uint32_t s = wstart[(uint64_t)i * pp.W + k];
+      const uint32_t c = wcnt[(uint64_t)i * pp.W + k];
+      const int64_t q1 = pp.win[k];
+      for (uint32_t e = 0; e < c; e++) {
+        const uint2 ent = entries[(uint64_t)s + e];
+        const uint64_t go = seq_off[ent.x];
+        const int64_t T = (int64_t)(seq_off[ent.x + 1] - go);
+        const int64_t jx = ent.y;
+        const int64_t p = jx - q1;
+        int64_t lim0 = 100 - pp.ww;  // cmd/muscato_screen/main.go:305 (q1 == 0 there)
+        if (lim0 > T) lim0 = T;
+        const bool fit0 = len <= lim0;
+        bool ok = p >= 0;
+        if (jx == 0) ok = ok && fit0; else ok = ok && (p + len <= T);
+        const uint32_t z = (p == 0 && !fit0) ? 1u : 0u;
+        const uint64_t gpos = go + (uint64_t)(p > 0 ? p : 0);
+        p_read[out] = ok ? i : PAIR_INVALID;
+        p_gpos[out] = (uint32_t)gpos;
+        p_meta[out] = (uint32_t)k | (z << 4) | ((uint32_t)(gpos >> 32) << 8);
+        p_gene[out] = ent.x;
+        out++;
+      }
     }
   }
+  block_add_u64(nvalid, &counters[0]);
 }
 
 // u32 mask of the bits of window [q1, q1+ww) (2 bits per base) that fall in record word j
@@ -509,49 +532,78 @@ __global__ __launch_bounds__(256) void k_confirm(
   p_nx[idx] = ok ? (uint16_t)nx : (uint16_t)NX_REJECT;
 }
 
-// One thread per read: best mismatch count over its accepted pairs, then emit the tuples
-// with nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60), or all accepted
-// tuples when apply_mmtol == 0.
-__global__ __launch_bounds__(256) void k_select(uint64_t r0, uint32_t n, PathParams pp,
-                                                const uint32_t* __restrict__ rbase,
-                                                const uint32_t* __restrict__ p_gpos,
-                                                const uint32_t* __restrict__ p_meta,
-                                                const uint32_t* __restrict__ p_gene,
-                                                const uint16_t* __restrict__ p_nx,
-                                                const uint64_t* __restrict__ seq_off,
-                                                musc_hit* __restrict__ hits,
-                                                unsigned long long* __restrict__ counters) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t acc = 0;
-  if (i < n) {
+// Per-read selection, two passes around a scan (no per-hit atomics, deterministic order).
+// Pass 1, one thread per read: best mismatch count over its accepted pairs and the number of
+// tuples with nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60), or all
+// accepted tuples when apply_mmtol == 0.
+__global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
+                                                    const uint32_t* __restrict__ rbase,
+                                                    const uint16_t* __restrict__ p_nx,
+                                                    uint32_t* __restrict__ hcnt,
+                                                    uint32_t* __restrict__ hthr,
+                                                    unsigned long long* __restrict__ counters) {
+  unsigned long long acc = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint64_t b = rbase[i], e = rbase[i + 1];
-    uint32_t best = NX_REJECT;
+    uint32_t best = NX_REJECT, na = 0;
     for (uint64_t j = b; j < e; j++) {
       const uint32_t v = p_nx[j];
       best = v < best ? v : best;
+      na += v != NX_REJECT;
     }
+    uint32_t cnt = 0, thr = 0;
     if (best != NX_REJECT) {
-      const uint32_t thr = pp.apply_mmtol ? best + (uint32_t)pp.mmtol : NX_REJECT - 1;
-      for (uint64_t j = b; j < e; j++) {
-        const uint32_t v = p_nx[j];
-        if (v == NX_REJECT) continue;
-        acc++;
-        if (v <= thr) {
-          const unsigned long long slot = atomicAdd(&counters[2], 1ull);
-          const uint32_t gene = p_gene[j];
-          const uint64_t gpos = (uint64_t)p_gpos[j] | ((uint64_t)((p_meta[j] >> 8) & 0xFFu) << 32);
-          musc_hit h;
-          h.read_idx = (uint32_t)(r0 + i);
-          h.gene_idx = gene;
-          h.pos = (uint32_t)(gpos - seq_off[gene]);
-          h.nmiss = v;
-          hits[slot] = h;
-        }
+      thr = pp.apply_mmtol ? best + (uint32_t)pp.mmtol : NX_REJECT - 1;
+      if (thr > NX_REJECT - 1) thr = NX_REJECT - 1;
+      if (!pp.apply_mmtol) {
+        cnt = na;
+      } else {
+        for (uint64_t j = b; j < e; j++) cnt += p_nx[j] <= thr;
       }
     }
+    hcnt[i] = cnt;
+    hthr[i] = cnt ? thr : 0xFFFFFFFFu;
+    acc += na;
   }
-  for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
-  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&counters[1], (unsigned long long)acc);
+  block_add_u64(acc, &counters[1]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hcnt[n] = 0;
+}
+
+// Pass 2, one thread per read: write its tuples at hits[counters[2] + hbase[i] ...].
+__global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uint32_t* __restrict__ rbase,
+                                              const uint32_t* __restrict__ hbase,
+                                              const uint32_t* __restrict__ hthr,
+                                              const uint32_t* __restrict__ p_gpos,
+                                              const uint32_t* __restrict__ p_meta,
+                                              const uint32_t* __restrict__ p_gene,
+                                              const uint16_t* __restrict__ p_nx,
+                                              const uint64_t* __restrict__ seq_off,
+                                              musc_hit* __restrict__ hits,
+                                              const unsigned long long* __restrict__ counters) {
+  const unsigned long long base = counters[2];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t thr = hthr[i];
+    if (thr == 0xFFFFFFFFu) continue;
+    unsigned long long slot = base + hbase[i];
+    const uint64_t b = rbase[i], e = rbase[i + 1];
+    for (uint64_t j = b; j < e; j++) {
+      const uint32_t v = p_nx[j];
+      if (v > thr) continue;  // NX_REJECT > thr always
+      const uint32_t gene = p_gene[j];
+      const uint64_t gpos = (uint64_t)p_gpos[j] | ((uint64_t)((p_meta[j] >> 8) & 0xFFu) << 32);
+      musc_hit h;
+      h.read_idx = (uint32_t)(r0 + i);
+      h.gene_idx = gene;
+      h.pos = (uint32_t)(gpos - seq_off[gene]);
+      h.nmiss = v;
+      hits[slot++] = h;
+    }
+  }
+}
+
+// counters[2] (hits so far) += hbase[n] (hits of this batch)
+__global__ void k_advance(const uint32_t* __restrict__ hbase, uint32_t n, unsigned long long* counters) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) counters[2] += hbase[n];
 }
 
 __global__ void k_rebase_hits(musc_hit* h, uint64_t n, uint32_t add) {
@@ -607,7 +659,7 @@ struct musc_ctx {
   uint32_t max_len = 0;
 
   // per-batch work buffers
-  DevBuf<uint32_t> wstart, wcnt, rtot, rbase, scan_tmp;
+  DevBuf<uint32_t> wstart, wcnt, rtot, rbase, scan_tmp, hcnt, hbase, hthr;
   DevBuf<uint32_t> p_read, p_gpos, p_meta, p_gene;
   DevBuf<uint16_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
@@ -825,6 +877,7 @@ void musc_destroy(musc_ctx* c) {
   free_db(c);
   free_reads(c);
   c->wstart.release(); c->wcnt.release(); c->rtot.release(); c->rbase.release(); c->scan_tmp.release();
+  c->hcnt.release(); c->hbase.release(); c->hthr.release();
   c->p_read.release(); c->p_gpos.release(); c->p_meta.release(); c->p_gene.release(); c->p_nx.release();
   c->nmiss_tab.release();
   c->hits.release();
@@ -1011,7 +1064,7 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
     offp = d_off;
   }
   HIPCHK(c, hipMemsetAsync(c->counters + 4, 0, 8, c->stream));
-  hipLaunchKernelGGL(k_max_len, dim3(nblk(nreads, 256)), dim3(256), 0, c->stream, offp, nreads, c->counters + 4);
+  hipLaunchKernelGGL(k_max_len, dim3(std::min(nblk(nreads, 256), MAX_GRID)), dim3(256), 0, c->stream, offp, nreads, c->counters + 4);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters + 4, 8, hipMemcpyDeviceToHost, c->stream));
   uint64_t first = 0, total = 0;
@@ -1169,11 +1222,14 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if ((rc = ensure(c, c->rtot, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->rbase, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)n + 1)))) return rc;
+    if ((rc = ensure(c, c->hcnt, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->hbase, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->hthr, (uint64_t)n + 1))) return rc;
 
     tm.begin(0);
     HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->rtot.p + n, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_seed, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp,
+    hipLaunchKernelGGL(k_seed, dim3(std::min(nblk(n, 256), MAX_GRID)), dim3(256), 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp,
                        c->idx_A, c->wstart.p, c->wcnt.p, c->rtot.p, c->counters);
     HIPCHK(c, hipGetLastError());
     tm.end(0);
@@ -1202,7 +1258,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
 
       tm.begin(2);
-      hipLaunchKernelGGL(k_expand, dim3(nblk(n, 256)), dim3(256), 0, c->stream, c->rd, r0, n, c->rw, pp,
+      hipLaunchKernelGGL(k_expand, dim3(std::min(nblk(n, 256), MAX_GRID)), dim3(256), 0, c->stream, c->rd, r0, n, c->rw, pp,
                          c->wstart.p, c->wcnt.p, c->rbase.p, c->idx_entries, c->seq_off, c->p_read.p, c->p_gpos.p,
                          c->p_meta.p, c->p_gene.p, c->counters);
       HIPCHK(c, hipGetLastError());
@@ -1223,11 +1279,21 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       c->stats.n_pairs += total;
       }
 
+      if (total) {
       tm.begin(4);
-      hipLaunchKernelGGL(k_select, dim3(nblk(n, 256)), dim3(256), 0, c->stream, r0, n, pp, c->rbase.p, c->p_gpos.p,
+      const dim3 sg(std::min(nblk(n, 256), MAX_GRID));
+      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->rbase.p, c->p_nx.p, c->hcnt.p,
+                         c->hthr.p, c->counters);
+      HIPCHK(c, hipGetLastError());
+      rc = scan_u32(c, c->hcnt.p, c->hbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_emit, sg, dim3(256), 0, c->stream, r0, n, c->rbase.p, c->hbase.p, c->hthr.p, c->p_gpos.p,
                          c->p_meta.p, c->p_gene.p, c->p_nx.p, c->seq_off, c->hits.p, c->counters);
       HIPCHK(c, hipGetLastError());
+      hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->hbase.p, n, c->counters);
+      HIPCHK(c, hipGetLastError());
       tm.end(4);
+      }
     }
     r0 += n;
   }
