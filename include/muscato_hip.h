@@ -74,7 +74,8 @@ typedef struct {
 typedef struct {
   uint64_t n_reads;         /* unique reads processed                                  */
   uint64_t n_read_windows;  /* (read, window) seeds that passed the length+entropy gate */
-  uint64_t n_pairs;         /* candidate (read, target position) pairs confirmed        */
+  uint64_t n_candidates;    /* index entries probed (k-mer hits incl. chance hits)      */
+  uint64_t n_pairs;         /* candidate pairs that reached the confirm kernel          */
   uint64_t n_accepted;      /* pairs with nmiss <= budget, after the union over windows */
   uint64_t n_hits;          /* tuples returned                                          */
   uint64_t n_overflow_blocks; /* (window,key) blocks that may exceed MaxMatches (0 = exact) */

@@ -34,7 +34,7 @@ class MuscParams(ctypes.Structure):
 class MuscStats(ctypes.Structure):
     _fields_ = [
         ("n_reads", ctypes.c_uint64), ("n_read_windows", ctypes.c_uint64),
-        ("n_pairs", ctypes.c_uint64), ("n_accepted", ctypes.c_uint64),
+        ("n_candidates", ctypes.c_uint64), ("n_pairs", ctypes.c_uint64), ("n_accepted", ctypes.c_uint64),
         ("n_hits", ctypes.c_uint64), ("n_overflow_blocks", ctypes.c_uint64),
         ("confirm_bytes", ctypes.c_uint64),
         ("confirm_launches", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),

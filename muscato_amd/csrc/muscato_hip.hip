@@ -70,7 +70,9 @@ DEV uint32_t bucket_of(const uint32_t* __restrict__ w, const uint32_t* __restric
     anymask |= mk;
     h = mix64(h ^ key ^ mix64(mk + 0x9E3779B97F4A7C15ull * (uint64_t)(c + 1)));
   }
-  if (direct && anymask == 0) return (uint32_t)key0;
+  // direct mode: first base in the most significant bits, so that bytewise-sorted reads
+  // (the order of reads_sorted.txt.sz) walk the table and the entry lists front to back
+  if (direct && anymask == 0) return (uint32_t)(__brevll(key0) >> (64 - nb));
   return (uint32_t)(h >> (64 - bits));
 }
 
@@ -263,12 +265,27 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ 
 // bumps A[b+1], leaving A[b] = start(b), A[b+1] = end(b).
 // ------------------------------------------------------------------------------------
 
+// One index entry (16 B, one dwordx4): everything k_expand needs about a window start
+// without touching the per-gene offset table.
+//   x gene   : target number
+//   y gposw  : global base offset of the window start (low 32 bits)
+//   z lr     : min(jx, 65535) | min(T - jx, 65535) << 16  (distances to the gene's two ends,
+//              saturated: window starts and read lengths are < 65535, so every comparison
+//              k_expand makes against them is exact)
+//   w flank  : the 8 bases left of the window (bits 0-15, base jx-1 in bits 14-15) and the
+//              8 bases right of it (bits 16-31, base jx+ww in bits 16-17), 2 bits each
+DEV uint32_t flank_left(const uint32_t* __restrict__ w, uint64_t base) {
+  // 8 bases ending just before base index `base` of plane w (zeros before the stream start)
+  if (base >= 8) return (uint32_t)ext64(w, 2 * (base - 8)) & 0xFFFFu;
+  return (uint32_t)(ext64(w, 0) << (2 * (8 - base))) & 0xFFFFu;
+}
+
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_index(const uint32_t* __restrict__ db2,
                                                const uint32_t* __restrict__ dbm2,
                                                const uint64_t* __restrict__ seq_off, uint32_t nseq,
                                                uint64_t nbases, int ww, int bits, int direct,
-                                               uint32_t* __restrict__ A, uint2* __restrict__ entries) {
+                                               uint32_t* __restrict__ A, uint4* __restrict__ entries) {
   __shared__ uint32_t s_g0;
   const uint64_t gfirst = (uint64_t)blockIdx.x * blockDim.x;
   if (threadIdx.x == 0) {
@@ -292,7 +309,10 @@ __global__ __launch_bounds__(256) void k_index(const uint32_t* __restrict__ db2,
     atomicAdd(&A[(uint64_t)b + 2], 1u);
   } else {
     const uint32_t slot = atomicAdd(&A[(uint64_t)b + 1], 1u);
-    entries[slot] = make_uint2(gene, (uint32_t)jx);
+    const uint64_t rem = e - g;  // T - jx
+    const uint32_t lr = (uint32_t)(jx > 65535 ? 65535 : jx) | ((uint32_t)(rem > 65535 ? 65535 : rem) << 16);
+    const uint32_t fl = flank_left(db2, g) | (((uint32_t)ext64(db2, 2 * (g + (uint64_t)ww)) & 0xFFFFu) << 16);
+    entries[slot] = make_uint4(gene, (uint32_t)g, lr, fl);
   }
 }
 
@@ -312,118 +332,230 @@ struct PathParams {
   uint32_t q1zero_mask;  // windows whose start is 0 (the pos-0 path of processSeq)
 };
 
-DEV uint32_t plane_code(const uint32_t* __restrict__ w, const uint32_t* __restrict__ m, uint32_t j) {
-  uint32_t c = (w[j >> 4] >> ((j & 15) * 2)) & 3u;
-  if (m && ((m[j >> 4] >> ((j & 15) * 2)) & 1u)) c = 4;
-  return c;
+// A read record: RW u32 words, bases (2 bits each) in words 0..RW-2, length in word RW-1.
+// RW > 0: the whole record sits in registers after two (or more) 16-byte loads -- the
+// thread-per-read kernels are bound by the number of memory instructions they issue (each
+// one touches 16+ cache lines per wave), not by arithmetic.  RW == 0: runtime stride, the
+// words are read from memory on demand.
+template <int RW>
+struct Rec {
+  uint32_t w[RW];
+  DEV void load(const uint32_t* __restrict__ p, int) {
+#pragma unroll
+    for (int q = 0; q < RW / 4; q++) {
+      const uint4 a = *reinterpret_cast<const uint4*>(p + 4 * q);
+      w[4 * q] = a.x; w[4 * q + 1] = a.y; w[4 * q + 2] = a.z; w[4 * q + 3] = a.w;
+    }
+  }
+  DEV uint32_t len() const { return w[RW - 1] & 0xFFFFu; }
+  // 64 bits from bit offset bo (bo is wave-uniform in every caller: selects, no scratch)
+  DEV uint64_t ext(uint32_t bo) const {
+    const int i = (int)(bo >> 5);
+    const uint32_t sh = bo & 31u;
+    uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int j = 0; j < RW; j++) {
+      a = (j == i) ? w[j] : a;
+      b = (j == i + 1) ? w[j] : b;
+      c = (j == i + 2) ? w[j] : c;
+    }
+    const uint64_t lo = (uint64_t)a | ((uint64_t)b << 32);
+    return sh ? (lo >> sh) | ((uint64_t)c << (64 - sh)) : lo;
+  }
+};
+
+template <>
+struct Rec<0> {
+  const uint32_t* __restrict__ p;
+  int rw;
+  DEV void load(const uint32_t* __restrict__ q, int rw_rt) { p = q; rw = rw_rt; }
+  DEV uint32_t len() const { return p[rw - 1] & 0xFFFFu; }
+  DEV uint64_t ext(uint32_t bo) const { return ext64(p, bo); }
+};
+
+// 8 bases ending just before base `base` of a record, like flank_left on a stream
+template <class R>
+DEV uint32_t rec_flank_left(const R& r, uint32_t base) {
+  if (base >= 8) return (uint32_t)r.ext(2 * (base - 8)) & 0xFFFFu;
+  return (uint32_t)(r.ext(0) << (2 * (8 - base))) & 0xFFFFu;
+}
+
+// bucket of the read window starting at base q1 (same function as bucket_of on the database)
+template <class R>
+DEV uint32_t rec_bucket(const R& r, const R& m, bool has_m, uint32_t q1, int ww, int bits, int direct) {
+  const int nb = 2 * ww;
+  uint64_t h = 0, anymask = 0, key0 = 0;
+  for (int c = 0; c < nb; c += 64) {
+    const int take = nb - c < 64 ? nb - c : 64;
+    const uint64_t key = r.ext(2 * q1 + c) & lowmask64(take);
+    const uint64_t mk = has_m ? (m.ext(2 * q1 + c) & lowmask64(take)) : 0ull;
+    if (c == 0) key0 = key;
+    anymask |= mk;
+    h = mix64(h ^ key ^ mix64(mk + 0x9E3779B97F4A7C15ull * (uint64_t)(c + 1)));
+  }
+  if (direct && anymask == 0) return (uint32_t)(__brevll(key0) >> (64 - nb));
+  return (uint32_t)(h >> (64 - bits));
 }
 
 // utils/entropy.go:5-40 on packed bases: number of distinct adjacent letter pairs over the
 // 5-letter alphabet {A,C,G,T,other}; the count does not depend on how letters are numbered.
-DEV int count_dinuc_packed(const uint32_t* __restrict__ w, const uint32_t* __restrict__ m,
-                           uint32_t q1, int ww) {
+template <class R>
+DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww) {
   uint32_t seen = 0;
-  uint32_t prev = plane_code(w, m, q1);
-  for (int i = 1; i < ww; i++) {
-    const uint32_t cur = plane_code(w, m, q1 + i);
-    seen |= 1u << (prev * 5 + cur);
-    prev = cur;
+  for (int c = 0; c + 1 < ww; c += 31) {  // 32-base chunks overlapping by one base
+    const int nbase = ww - c < 32 ? ww - c : 32;
+    const uint64_t key = r.ext(2 * (q1 + c));
+    const uint64_t mk = has_m ? (m.ext(2 * (q1 + c)) & lowmask64(2 * nbase)) : 0ull;
+    if (mk == 0) {
+      // no X in the chunk: a pair of bases is a 4-bit code, 16 possible pairs
+      uint32_t s16 = 0;
+      for (int i = 0; i + 1 < nbase; i++) s16 |= 1u << ((uint32_t)(key >> (2 * i)) & 15u);
+      // map the 16-bit set of (a + 4b) onto the 25-bit set of (a*5 + b)
+      for (int q = 0; q < 16; q++)
+        if ((s16 >> q) & 1u) seen |= 1u << ((q & 3) * 5 + (q >> 2));
+    } else {
+      for (int i = 0; i + 1 < nbase; i++) {
+        const uint32_t a = ((mk >> (2 * i)) & 1u) ? 4u : ((uint32_t)(key >> (2 * i)) & 3u);
+        const uint32_t b = ((mk >> (2 * i + 2)) & 1u) ? 4u : ((uint32_t)(key >> (2 * i + 2)) & 3u);
+        seen |= 1u << (a * 5 + b);
+      }
+    }
   }
   return __popc(seen);
 }
 
-// One thread per read: which windows take part (cmd/muscato_window_reads/main.go:106-118 ==
-// cmd/muscato_screen/main.go:174-185) and which index bucket each one probes.
-__global__ __launch_bounds__(256) void k_seed(uint32_t* __restrict__ rd,
+#define WSC_VALID 0x80000000u
+
+// k_seed -- one thread per read: which windows take part
+// (cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185) and the
+// index bucket [start, start+count) each one probes.  wsc[i*W+k] = (start, count | VALID).
+template <int RW>
+__global__ __launch_bounds__(256) void k_seed(const uint32_t* __restrict__ rd,
                                               const uint32_t* __restrict__ rdm, uint64_t r0,
-                                              uint32_t n, int rw, PathParams pp,
+                                              uint32_t n, int rw_rt, PathParams pp,
                                               const uint32_t* __restrict__ A,
-                                              uint32_t* __restrict__ wstart,
-                                              uint32_t* __restrict__ wcnt,
-                                              uint32_t* __restrict__ rtot,
+                                              uint2* __restrict__ wsc, uint32_t* __restrict__ rtot,
                                               unsigned long long* __restrict__ counters) {
+  const int rw = RW ? RW : rw_rt;
+  const bool has_m = rdm != nullptr;
   unsigned long long t64 = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint64_t r = r0 + i;
-    uint32_t* rec = rd + r * (uint64_t)rw;
-    const uint32_t* recm = rdm ? rdm + r * (uint64_t)rw : nullptr;
-    const uint32_t len = rec[rw - 1] & 0xFFFFu;
-    uint32_t valid = 0, tot = 0;
+    Rec<RW> rec;
+    rec.load(rd + r * (uint64_t)rw, rw);
+    Rec<RW> recm = rec;  // placeholder, only read under has_m
+    if (has_m) recm.load(rdm + r * (uint64_t)rw, rw);
+    const uint32_t len = rec.len();
+    uint32_t tot = 0;
     for (int k = 0; k < pp.W; k++) {
       const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
       uint32_t s = 0, c = 0;
       if (len >= q2) {
-        const bool ok = pp.min_dinuc <= 0 || count_dinuc_packed(rec, recm, q1, pp.ww) >= pp.min_dinuc;
+        const bool ok = pp.min_dinuc <= 0 || rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
         if (ok) {
-          valid |= 1u << k;
-          const uint32_t b = bucket_of(rec, recm, 2ull * q1, pp.ww, pp.bits, pp.direct);
-          s = A[b];
-          c = A[(uint64_t)b + 1] - s;
+          const uint32_t b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+          // A[b], A[b+1]: one 8-byte load (dword aligned)
+          struct __attribute__((packed, aligned(4))) u32x2_u { uint32_t x, y; };
+          const u32x2_u se = *reinterpret_cast<const u32x2_u*>(A + b);
+          s = se.x;
+          c = (se.y - se.x) | WSC_VALID;
         }
       }
-      wstart[(uint64_t)i * pp.W + k] = s;
-      wcnt[(uint64_t)i * pp.W + k] = c;
-      tot += c;
+      wsc[(uint64_t)i * pp.W + k] = make_uint2(s, c);
+      tot += c & ~WSC_VALID;
     }
-    rec[rw - 1] = len | (valid << 16);
     rtot[i] = tot;
     t64 += tot;
   }
-  // 64-bit total of candidate pairs of this launch (the u32 scan could wrap)
+  // 64-bit total of candidate slots of this launch (the u32 scan could wrap)
   block_add_u64(t64, &counters[3]);
 }
 
-#define PAIR_INVALID 0xFFFFFFFFu
 #define NX_REJECT 0xFFFFu
 
-// One thread per read: walk its buckets and write one candidate pair per index entry.
+// Pair descriptor (16 B): x = read index within the batch, y = global base offset of the
+// placement, z = window k | z-flag << 4 | read's valid-window mask << 16, w = gene.
+
+// k_expand -- one thread per read: walk its buckets and stage one descriptor per surviving
+// index entry at sdesc[rbase[i] ...]; vcnt[i] = number staged.
 // The fit rules of cmd/muscato_screen/main.go:294-316 (target position 0, literal 100) and
 // :335-363 + cmd/muscato_confirm/main.go:201-203 (read must end inside the target) are
-// applied here, where the target length is at hand.
+// applied here from the distances stored in the entry.  A candidate whose 8+8 flanking bases
+// already disagree with the read in more places than the read's whole mismatch budget can
+// never be accepted by cdiff (cmd/muscato_confirm/main.go:205-211) and is dropped here, before
+// it costs a target gather (chance k-mer hits are about half of all candidates).  The flank
+// test never over-counts: an X is stored as code 0 on both sides.
+template <int RW>
 __global__ __launch_bounds__(256) void k_expand(const uint32_t* __restrict__ rd, uint64_t r0,
-                                                uint32_t n, int rw, PathParams pp,
-                                                const uint32_t* __restrict__ wstart,
-                                                const uint32_t* __restrict__ wcnt,
+                                                uint32_t n, int rw_rt, PathParams pp,
+                                                const uint16_t* __restrict__ nmiss_tab,
+                                                const uint2* __restrict__ wsc,
                                                 const uint32_t* __restrict__ rbase,
-                                                const uint2* __restrict__ entries,
-                                                const uint64_t* __restrict__ seq_off,
-                                                uint32_t* __restrict__ p_read,
-                                                uint32_t* __restrict__ p_gpos,
-                                                uint32_t* __restrict__ p_meta,
-                                                uint32_t* __restrict__ p_gene,
+                                                const uint4* __restrict__ entries,
+                                                uint4* __restrict__ sdesc, uint32_t* __restrict__ vcnt,
                                                 unsigned long long* __restrict__ counters) {
-  unsigned long long nvalid = 0;
+  const int rw = RW ? RW : rw_rt;
+  unsigned long long nvalid = 0, npair = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t rmeta = rd[(r0 + i) * (uint64_t)rw + rw - 1];
-    nvalid += __popc(rmeta >> 16);
-    const int64_t len = rmeta & 0xFFFFu;
+    Rec<RW> rec;
+    rec.load(rd + (r0 + i) * (uint64_t)rw, rw);
+    const int len = (int)rec.len();
+    const uint32_t budget = nmiss_tab[len];
     uint64_t out = rbase[i];
+    const uint64_t out0 = out;
+    uint32_t valid = 0;
+    for (int k = 0; k < pp.W; k++) valid |= (wsc[(uint64_t)i * pp.W + k].y >> 31) << k;
+    nvalid += __popc(valid);
     for (int k = 0; k < pp.W; k++) {
-      const uint32_t s = wstart[(uint64_t)i * pp.W + k];
-      const uint32_t c = wcnt[(uint64_t)i * pp.W + k];
-      const int64_t q1 = pp.win[k];
+      const uint2 sc = wsc[(uint64_t)i * pp.W + k];
+      const uint32_t c = sc.y & ~WSC_VALID;
+      if (c == 0) continue;
+      const int q1 = pp.win[k], q2 = q1 + pp.ww;
+      // the read's own flanks and which of their bases exist
+      const int nl = q1 < 8 ? q1 : 8;                                   // bases left of the window
+      const int nr = len - q2 < 8 ? (len - q2 < 0 ? 0 : len - q2) : 8;  // bases right of it
+      const uint32_t rfl = rec_flank_left(rec, (uint32_t)q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+      const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
+                             ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
       for (uint32_t e = 0; e < c; e++) {
-        const uint2 ent = entries[(uint64_t)s + e];
-        const uint64_t go = seq_off[ent.x];
-        const int64_t T = (int64_t)(seq_off[ent.x + 1] - go);
-        const int64_t jx = ent.y;
-        const int64_t p = jx - q1;
-        int64_t lim0 = 100 - pp.ww;  // cmd/muscato_screen/main.go:305 (q1 == 0 there)
-        if (lim0 > T) lim0 = T;
+        const uint4 ent = entries[(uint64_t)sc.x + e];
+        const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
+        int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
+        const int tcap = left + right;  // target length, saturated (exact below 65535)
+        if (lim0 > tcap) lim0 = tcap;
         const bool fit0 = len <= lim0;
-        bool ok = p >= 0;
-        if (jx == 0) ok = ok && fit0; else ok = ok && (p + len <= T);
-        const uint32_t z = (p == 0 && !fit0) ? 1u : 0u;
-        const uint64_t gpos = go + (uint64_t)(p > 0 ? p : 0);
-        p_read[out] = ok ? i : PAIR_INVALID;
-        p_gpos[out] = (uint32_t)gpos;
-        p_meta[out] = (uint32_t)k | (z << 4) | ((uint32_t)(gpos >> 32) << 8);
-        p_gene[out] = ent.x;
-        out++;
+        bool ok = q1 <= left;                 // p = jx - q1 >= 0
+        if (left == 0) ok = ok && fit0;       // window at target position 0: pos-0 path
+        else ok = ok && (len - q1 <= right);  // p + len <= T
+        const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
+        const uint32_t x = rfl ^ ent.w;
+        const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
+        ok = ok && ((uint32_t)__popc(d) <= budget);
+        if (ok) {
+          sdesc[out] = make_uint4(i, ent.y - (uint32_t)q1, (uint32_t)k | (z << 4) | (valid << 16), ent.x);
+          out++;
+        }
       }
     }
+    vcnt[i] = (uint32_t)(out - out0);
+    npair += out - out0;
   }
   block_add_u64(nvalid, &counters[0]);
+  block_add_u64(npair, &counters[4]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) vcnt[n] = 0;
+}
+
+// k_compact -- one thread per read: move its staged descriptors to their compact position,
+// so that k_confirm only sees surviving pairs and a read's pairs stay adjacent.
+__global__ __launch_bounds__(256) void k_compact(uint32_t n, const uint32_t* __restrict__ rbase,
+                                                 const uint32_t* __restrict__ cbase,
+                                                 const uint4* __restrict__ sdesc,
+                                                 uint4* __restrict__ cdesc) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t c0 = cbase[i], c1 = cbase[i + 1];
+    const uint64_t s0 = rbase[i];
+    for (uint32_t j = c0; j < c1; j++) cdesc[j] = sdesc[s0 + (j - c0)];
+  }
 }
 
 // u32 mask of the bits of window [q1, q1+ww) (2 bits per base) that fall in record word j
@@ -440,36 +572,34 @@ struct __attribute__((packed, aligned(4))) u32x4_u {
   uint32_t x, y, z, w;
 };
 
-// The confirm kernel: one lane per candidate pair.  Loads the 2-bit read record (aligned,
-// neighbouring lanes mostly share it) and the target span at an arbitrary base offset
-// (dword-aligned 16-byte gathers + funnel shift), XOR + popcount = cdiff over the whole read
+// k_confirm -- one lane per candidate pair.  Loads the 2-bit read record (aligned, neighbouring
+// lanes mostly share it) and the target span at an arbitrary base offset (dword-aligned
+// 16-byte gathers + funnel shift), XOR + popcount = cdiff over the whole read
 // (cmd/muscato_confirm/main.go:151-159, 205-211; X==X through the mask plane), then decides
 // whether THIS window is the first window of the read that the reference would have emitted
 // the tuple through (exact window key + fit), which makes the union over windows a set
-// without a sort.  RW = record words (compile time) or 0 = runtime stride.
+// without a sort.  RW = record words (compile time) or 0 = runtime stride.  The pair count
+// comes from device memory (cbase[n]) so that no host round trip sits in front of the launch.
 template <int RW, bool MASK>
 __global__ __launch_bounds__(256) void k_confirm(
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
     const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, int rw_rt,
-    PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint32_t* __restrict__ p_read,
-    const uint32_t* __restrict__ p_gpos, const uint32_t* __restrict__ p_meta,
-    uint16_t* __restrict__ p_nx, uint64_t npairs) {
+    PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
+    uint16_t* __restrict__ p_nx, const uint32_t* __restrict__ npairs_dev) {
   const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= npairs) return;
-  const uint32_t ri = p_read[idx];
-  if (ri == PAIR_INVALID) {
-    p_nx[idx] = NX_REJECT;
-    return;
-  }
+  if (idx >= *npairs_dev) return;
+  const uint4 ds = cdesc[idx];
+  const uint32_t ri = ds.x;
   const int rw = RW ? RW : rw_rt;
-  const uint32_t meta = p_meta[idx];
-  const uint64_t gpos = (uint64_t)p_gpos[idx] | ((uint64_t)((meta >> 8) & 0xFFu) << 32);
-  const uint32_t k = meta & 15u, z = (meta >> 4) & 1u;
+  const uint64_t gpos = ds.y;
+  const uint32_t k = ds.z & 15u, z = (ds.z >> 4) & 1u;
   const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)rw;
   const uint64_t widx = gpos >> 4;
   const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
+  uint32_t exact = ds.z >> 16;
+  if (z) exact &= ~pp.q1zero_mask;
 
-  uint32_t nx = 0, rmeta, exact;
+  uint32_t nx = 0, len;
   if constexpr (RW != 0) {
     // ---- static stride: whole record and span in registers, 16-byte loads
     uint32_t r[RW], t[RW], rm[RW], tm[RW];
@@ -486,10 +616,8 @@ __global__ __launch_bounds__(256) void k_confirm(
         tm[4 * q] = d.x; tm[4 * q + 1] = d.y; tm[4 * q + 2] = d.z; tm[4 * q + 3] = d.w;
       }
     }
-    rmeta = r[RW - 1];
-    const int len2 = 2 * (int)(rmeta & 0xFFFFu);
-    exact = rmeta >> 16;
-    if (z) exact &= ~pp.q1zero_mask;
+    len = r[RW - 1] & 0xFFFFu;
+    const int len2 = 2 * (int)len;
 #pragma unroll
     for (int j = 0; j < RW - 1; j++) {
       const uint32_t tj = __funnelshift_r(t[j], t[j + 1], sh);
@@ -504,10 +632,8 @@ __global__ __launch_bounds__(256) void k_confirm(
     }
   } else {
     // ---- runtime stride (reads longer than the compiled strides): streaming words
-    rmeta = rec[rw - 1];
-    const int len2 = 2 * (int)(rmeta & 0xFFFFu);
-    exact = rmeta >> 16;
-    if (z) exact &= ~pp.q1zero_mask;
+    len = rec[rw - 1] & 0xFFFFu;
+    const int len2 = 2 * (int)len;
     const uint32_t* __restrict__ recm = MASK ? rdm + (r0 + ri) * (uint64_t)rw : nullptr;
     uint32_t tlo = db2[widx], tmlo = MASK ? dbm2[widx] : 0u;
     for (int j = 0; j < rw - 1; j++) {
@@ -528,8 +654,8 @@ __global__ __launch_bounds__(256) void k_confirm(
     }
   }
   const uint32_t kmin = exact ? (uint32_t)(__ffs(exact) - 1) : 0xFFu;
-  const bool ok = (kmin == k) && (nx <= nmiss_tab[rmeta & 0xFFFFu]);
-  p_nx[idx] = ok ? (uint16_t)nx : (uint16_t)NX_REJECT;
+  const bool ok = (kmin == k) && (nx <= nmiss_tab[len]);
+  __builtin_nontemporal_store(ok ? (uint16_t)nx : (uint16_t)NX_REJECT, &p_nx[idx]);
 }
 
 // Per-read selection, two passes around a scan (no per-hit atomics, deterministic order).
@@ -537,16 +663,16 @@ __global__ __launch_bounds__(256) void k_confirm(
 // tuples with nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60), or all
 // accepted tuples when apply_mmtol == 0.
 __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
-                                                    const uint32_t* __restrict__ rbase,
+                                                    const uint32_t* __restrict__ cbase,
                                                     const uint16_t* __restrict__ p_nx,
                                                     uint32_t* __restrict__ hcnt,
                                                     uint32_t* __restrict__ hthr,
                                                     unsigned long long* __restrict__ counters) {
   unsigned long long acc = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t b = rbase[i], e = rbase[i + 1];
+    const uint32_t b = cbase[i], e = cbase[i + 1];
     uint32_t best = NX_REJECT, na = 0;
-    for (uint64_t j = b; j < e; j++) {
+    for (uint32_t j = b; j < e; j++) {
       const uint32_t v = p_nx[j];
       best = v < best ? v : best;
       na += v != NX_REJECT;
@@ -558,7 +684,7 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
       if (!pp.apply_mmtol) {
         cnt = na;
       } else {
-        for (uint64_t j = b; j < e; j++) cnt += p_nx[j] <= thr;
+        for (uint32_t j = b; j < e; j++) cnt += p_nx[j] <= thr;
       }
     }
     hcnt[i] = cnt;
@@ -570,12 +696,10 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
 }
 
 // Pass 2, one thread per read: write its tuples at hits[counters[2] + hbase[i] ...].
-__global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uint32_t* __restrict__ rbase,
+__global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uint32_t* __restrict__ cbase,
                                               const uint32_t* __restrict__ hbase,
                                               const uint32_t* __restrict__ hthr,
-                                              const uint32_t* __restrict__ p_gpos,
-                                              const uint32_t* __restrict__ p_meta,
-                                              const uint32_t* __restrict__ p_gene,
+                                              const uint4* __restrict__ cdesc,
                                               const uint16_t* __restrict__ p_nx,
                                               const uint64_t* __restrict__ seq_off,
                                               musc_hit* __restrict__ hits,
@@ -585,18 +709,17 @@ __global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uin
     const uint32_t thr = hthr[i];
     if (thr == 0xFFFFFFFFu) continue;
     unsigned long long slot = base + hbase[i];
-    const uint64_t b = rbase[i], e = rbase[i + 1];
-    for (uint64_t j = b; j < e; j++) {
+    const uint32_t b = cbase[i], e = cbase[i + 1];
+    for (uint32_t j = b; j < e; j++) {
       const uint32_t v = p_nx[j];
       if (v > thr) continue;  // NX_REJECT > thr always
-      const uint32_t gene = p_gene[j];
-      const uint64_t gpos = (uint64_t)p_gpos[j] | ((uint64_t)((p_meta[j] >> 8) & 0xFFu) << 32);
+      const uint4 ds = cdesc[j];
       musc_hit h;
       h.read_idx = (uint32_t)(r0 + i);
-      h.gene_idx = gene;
-      h.pos = (uint32_t)(gpos - seq_off[gene]);
+      h.gene_idx = ds.w;
+      h.pos = (uint32_t)((uint64_t)ds.y - seq_off[ds.w]);
       h.nmiss = v;
-      hits[slot++] = h;
+      *reinterpret_cast<uint4*>(&hits[slot++]) = make_uint4(h.read_idx, h.gene_idx, h.pos, h.nmiss);
     }
   }
 }
@@ -648,7 +771,7 @@ struct musc_ctx {
   // index
   int idx_ww = 0, idx_bits = 0, idx_direct = 0;
   uint32_t* idx_A = nullptr;
-  uint2* idx_entries = nullptr;
+  uint4* idx_entries = nullptr;
   uint64_t idx_n = 0;
 
   // reads
@@ -659,8 +782,9 @@ struct musc_ctx {
   uint32_t max_len = 0;
 
   // per-batch work buffers
-  DevBuf<uint32_t> wstart, wcnt, rtot, rbase, scan_tmp, hcnt, hbase, hthr;
-  DevBuf<uint32_t> p_read, p_gpos, p_meta, p_gene;
+  DevBuf<uint2> wsc;
+  DevBuf<uint32_t> rtot, rbase, vcnt, cbase, scan_tmp, hcnt, hbase, hthr;
+  DevBuf<uint4> sdesc, cdesc;
   DevBuf<uint16_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
   unsigned long long* counters = nullptr;  // [0] valid windows [1] accepted [2] hit cursor
@@ -669,7 +793,7 @@ struct musc_ctx {
   DevBuf<musc_hit> hits;
   uint64_t nhits = 0;
 
-  uint32_t batch_reads = 4u << 20;
+  uint32_t batch_reads = 16u << 20;
   musc_stats stats;
 };
 
@@ -820,14 +944,33 @@ int check_params(musc_ctx* c, const musc_params* P) {
 }
 
 template <int RW>
-void launch_confirm(musc_ctx* c, bool mask, uint64_t r0, const PathParams& pp, uint64_t npairs) {
-  const dim3 grid(nblk(npairs, 256)), block(256);
-  if (mask)
-    hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                       c->rw, pp, c->nmiss_tab.p, c->p_read.p, c->p_gpos.p, c->p_meta.p, c->p_nx.p, npairs);
-  else
-    hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                       c->rw, pp, c->nmiss_tab.p, c->p_read.p, c->p_gpos.p, c->p_meta.p, c->p_nx.p, npairs);
+void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp, uint64_t slots) {
+  const dim3 block(256), rgrid(std::min(nblk(n, 256), MAX_GRID));
+  if (stage == 0) {
+    hipLaunchKernelGGL((k_seed<RW>), rgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp, c->idx_A,
+                       c->wsc.p, c->rtot.p, c->counters);
+  } else if (stage == 1) {
+    hipLaunchKernelGGL((k_expand<RW>), rgrid, block, 0, c->stream, c->rd, r0, n, c->rw, pp, c->nmiss_tab.p,
+                       c->wsc.p, c->rbase.p, c->idx_entries, c->sdesc.p, c->vcnt.p, c->counters);
+  } else {
+    const dim3 grid(nblk(slots, 256));
+    if (mask)
+      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->p_nx.p, c->cbase.p + n);
+    else
+      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->p_nx.p, c->cbase.p + n);
+  }
+}
+
+void launch_stage(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp, uint64_t slots) {
+  switch (c->rw) {
+    case 4: launch_path<4>(c, stage, mask, r0, n, pp, slots); break;
+    case 8: launch_path<8>(c, stage, mask, r0, n, pp, slots); break;
+    case 12: launch_path<12>(c, stage, mask, r0, n, pp, slots); break;
+    case 16: launch_path<16>(c, stage, mask, r0, n, pp, slots); break;
+    default: launch_path<0>(c, stage, mask, r0, n, pp, slots); break;
+  }
 }
 
 }  // namespace
@@ -876,9 +1019,9 @@ void musc_destroy(musc_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_db(c);
   free_reads(c);
-  c->wstart.release(); c->wcnt.release(); c->rtot.release(); c->rbase.release(); c->scan_tmp.release();
-  c->hcnt.release(); c->hbase.release(); c->hthr.release();
-  c->p_read.release(); c->p_gpos.release(); c->p_meta.release(); c->p_gene.release(); c->p_nx.release();
+  c->wsc.release(); c->rtot.release(); c->rbase.release(); c->vcnt.release(); c->cbase.release();
+  c->scan_tmp.release(); c->hcnt.release(); c->hbase.release(); c->hthr.release();
+  c->sdesc.release(); c->cdesc.release(); c->p_nx.release();
   c->nmiss_tab.release();
   c->hits.release();
   if (c->counters) (void)hipFree(c->counters);
@@ -1014,7 +1157,7 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   const unsigned blocks = nblk(c->nbases, 256);
   if (c->nbases) {
     hipLaunchKernelGGL(k_index<false>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
-                       c->nbases, ww, bits, direct, c->idx_A, (uint2*)nullptr);
+                       c->nbases, ww, bits, direct, c->idx_A, (uint4*)nullptr);
     HIPCHK(c, hipGetLastError());
   }
   int rc = ensure(c, c->scan_tmp, scan_tmp_elems(nb + 2));
@@ -1025,7 +1168,7 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   HIPCHK(c, hipMemcpyAsync(&total, c->idx_A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->idx_n = total;
-  HIPCHK(c, hipMalloc((void**)&c->idx_entries, ((uint64_t)total + 16) * sizeof(uint2)));
+  HIPCHK(c, hipMalloc((void**)&c->idx_entries, ((uint64_t)total + 16) * sizeof(uint4)));
   if (c->nbases) {
     hipLaunchKernelGGL(k_index<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
                        c->nbases, ww, bits, direct, c->idx_A, c->idx_entries);
@@ -1211,16 +1354,18 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipMemsetAsync(c->dbm2, 0, (c->db_words + 64) * 4, c->stream));
   }
 
+  uint64_t n_slots = 0;  // candidate slots incl. the ones k_expand rejected
   const uint64_t PAIR_CAP = 1ull << 30;  // pairs per batch (19 B of work buffers each)
   uint64_t r0 = 0;
   uint32_t bsz = c->batch_reads;
   while (r0 < c->nreads) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
     const int W = pp.W;
-    if ((rc = ensure(c, c->wstart, (uint64_t)n * W))) return rc;
-    if ((rc = ensure(c, c->wcnt, (uint64_t)n * W))) return rc;
+    if ((rc = ensure(c, c->wsc, (uint64_t)n * W))) return rc;
     if ((rc = ensure(c, c->rtot, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->rbase, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->vcnt, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->cbase, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)n + 1)))) return rc;
     if ((rc = ensure(c, c->hcnt, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->hbase, (uint64_t)n + 1))) return rc;
@@ -1229,8 +1374,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     tm.begin(0);
     HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->rtot.p + n, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_seed, dim3(std::min(nblk(n, 256), MAX_GRID)), dim3(256), 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp,
-                       c->idx_A, c->wstart.p, c->wcnt.p, c->rtot.p, c->counters);
+    launch_stage(c, 0, mask, r0, n, pp, 0);
     HIPCHK(c, hipGetLastError());
     tm.end(0);
     tm.begin(1);
@@ -1240,69 +1384,65 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 3, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&c->h_pinned[1], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const uint64_t total = c->h_pinned[0];
+    const uint64_t total = c->h_pinned[0];  // candidate slots of this batch
     const uint64_t hits_so_far = c->h_pinned[1];
     if (total > PAIR_CAP) {
-      // too many candidate pairs for one launch: retry this range with half the reads
+      // too many candidates for one launch: retry this range with half the reads
       if (n == 1) return fail(c, 6, "one read has %llu candidate pairs (> 2^30)", (unsigned long long)total);
       bsz = n / 2;
       continue;
     }
     c->stats.n_batches++;
-    {
-      if ((rc = ensure(c, c->p_read, total))) return rc;
-      if ((rc = ensure(c, c->p_gpos, total))) return rc;
-      if ((rc = ensure(c, c->p_meta, total))) return rc;
-      if ((rc = ensure(c, c->p_gene, total))) return rc;
-      if ((rc = ensure(c, c->p_nx, total))) return rc;
-      if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
+    n_slots += total;
+    if ((rc = ensure(c, c->sdesc, total))) return rc;
+    if ((rc = ensure(c, c->cdesc, total))) return rc;
+    if ((rc = ensure(c, c->p_nx, total))) return rc;
+    if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
 
+    tm.begin(2);
+    launch_stage(c, 1, mask, r0, n, pp, 0);
+    HIPCHK(c, hipGetLastError());
+    tm.end(2);
+    tm.begin(1);
+    rc = scan_u32(c, c->vcnt.p, c->cbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
+    if (rc) return rc;
+    tm.end(1);
+    if (total) {
+      const dim3 sg(std::min(nblk(n, 256), MAX_GRID));
       tm.begin(2);
-      hipLaunchKernelGGL(k_expand, dim3(std::min(nblk(n, 256), MAX_GRID)), dim3(256), 0, c->stream, c->rd, r0, n, c->rw, pp,
-                         c->wstart.p, c->wcnt.p, c->rbase.p, c->idx_entries, c->seq_off, c->p_read.p, c->p_gpos.p,
-                         c->p_meta.p, c->p_gene.p, c->counters);
+      hipLaunchKernelGGL(k_compact, sg, dim3(256), 0, c->stream, n, c->rbase.p, c->cbase.p, c->sdesc.p, c->cdesc.p);
       HIPCHK(c, hipGetLastError());
       tm.end(2);
 
-      if (total) {
       tm.begin(3);
-      switch (c->rw) {
-        case 4: launch_confirm<4>(c, mask, r0, pp, total); break;
-        case 8: launch_confirm<8>(c, mask, r0, pp, total); break;
-        case 12: launch_confirm<12>(c, mask, r0, pp, total); break;
-        case 16: launch_confirm<16>(c, mask, r0, pp, total); break;
-        default: launch_confirm<0>(c, mask, r0, pp, total); break;
-      }
+      launch_stage(c, 2, mask, r0, n, pp, total);
       HIPCHK(c, hipGetLastError());
       tm.end(3);
       c->stats.confirm_launches++;
-      c->stats.n_pairs += total;
-      }
 
-      if (total) {
       tm.begin(4);
-      const dim3 sg(std::min(nblk(n, 256), MAX_GRID));
-      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->rbase.p, c->p_nx.p, c->hcnt.p,
+      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->cbase.p, c->p_nx.p, c->hcnt.p,
                          c->hthr.p, c->counters);
       HIPCHK(c, hipGetLastError());
       rc = scan_u32(c, c->hcnt.p, c->hbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_emit, sg, dim3(256), 0, c->stream, r0, n, c->rbase.p, c->hbase.p, c->hthr.p, c->p_gpos.p,
-                         c->p_meta.p, c->p_gene.p, c->p_nx.p, c->seq_off, c->hits.p, c->counters);
+      hipLaunchKernelGGL(k_emit, sg, dim3(256), 0, c->stream, r0, n, c->cbase.p, c->hbase.p, c->hthr.p, c->cdesc.p,
+                         c->p_nx.p, c->seq_off, c->hits.p, c->counters);
       HIPCHK(c, hipGetLastError());
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->hbase.p, n, c->counters);
       HIPCHK(c, hipGetLastError());
       tm.end(4);
-      }
     }
     r0 += n;
   }
   HIPCHK(c, hipEventRecord(ev1, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 3 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 5 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stats.n_read_windows = c->h_pinned[0];
   c->stats.n_accepted = c->h_pinned[1];
   c->stats.n_hits = c->nhits = c->h_pinned[2];
+  c->stats.n_pairs = c->h_pinned[4];
+  c->stats.n_candidates = n_slots;
   c->stats.ms_seed = tm.total(0);
   c->stats.ms_scan = tm.total(1);
   c->stats.ms_expand = tm.total(2);

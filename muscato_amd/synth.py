@@ -112,6 +112,29 @@ def gen_unique_reads(wl: Workload, targets_ascii: torch.Tensor, device, seed: in
     return out
 
 
+def sort_reads(reads: torch.Tensor) -> torch.Tensor:
+    """Bytewise (LC_ALL=C) sort of fixed-length ASCII reads -- the order of the reference's
+    reads_sorted.txt.sz, which is what its hot path consumes (cmd/muscato/main.go:180-189).
+    LSD radix over 25-base digits; A<C<G<T in ASCII, so 2-bit codes keep the order."""
+    n, L = reads.shape
+    dev = reads.device
+    code = torch.zeros(256, dtype=torch.int64, device=dev)
+    for i, c in enumerate(_ASCII):
+        code[c] = i
+    perm = torch.arange(n, device=dev)
+    nd = (L + 24) // 25
+    for d in range(nd - 1, -1, -1):
+        lo, hi = d * 25, min(L, d * 25 + 25)
+        key = torch.zeros(n, dtype=torch.int64, device=dev)
+        for j in range(lo, hi):
+            key = key * 4 + code[reads[:, j].long()]
+        key = key * (4 ** (25 - (hi - lo)))
+        order = torch.sort(key[perm], stable=True).indices
+        perm = perm[order]
+        del key, order
+    return reads[perm]
+
+
 def offsets_for(n: int, length: int, device) -> torch.Tensor:
     """uint64 offsets [n+1] of fixed-length sequences, stored in an int64 tensor."""
     return torch.arange(0, n + 1, dtype=torch.int64, device=device) * length
