@@ -67,7 +67,10 @@ typedef struct {
    * 1: additionally keep, per read, only nmiss <= best+MMTol = matches.txt
    *    (cmd/muscato_combine_windows/main.go:36-60). */
   int32_t apply_mmtol;
-  int32_t reserved[5];
+  /* Addition (the reference has no such flag; BASELINE.json's --MaxMismatch): 0 = budget from
+   * PMatch as above; v > 0 = every read may have at most v-1 mismatches. */
+  int32_t max_mismatch_p1;
+  int32_t reserved[4];
 } musc_params;
 
 /* Counters and device timings of the last musc_match* call on a context. */

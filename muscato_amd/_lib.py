@@ -27,7 +27,8 @@ class MuscParams(ctypes.Structure):
         ("match_mode", ctypes.c_int32),
         ("mmtol", ctypes.c_int32),
         ("apply_mmtol", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 5),
+        ("max_mismatch_p1", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 

@@ -49,6 +49,7 @@ class Config:
     SortMem: str = ""
     NoCleanTemp: bool = False
     CPUProfile: bool = False
+    MaxMismatch: int = -1  # addition: absolute mismatch budget (overrides PMatch when >= 0)
 
     @classmethod
     def from_json(cls, text) -> "Config":
@@ -105,6 +106,7 @@ class Config:
         p.match_mode = 1 if c.MatchMode == "first" else 0
         p.mmtol = int(c.MMTol)
         p.apply_mmtol = 1 if apply_mmtol else 0
+        p.max_mismatch_p1 = c.MaxMismatch + 1 if c.MaxMismatch >= 0 else 0
         return p
 
 

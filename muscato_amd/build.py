@@ -26,14 +26,37 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
+HOST = os.path.join(CSRC, "host")
+BIN = os.path.join(HERE, "bin")
+HOST_HEADERS = [os.path.join(HOST, "muscato_host.hpp"), os.path.join(HOST, "sz.hpp")]
+TOOLS = {"muscato": "muscato_cli.cpp", "muscato_prep_targets": "muscato_prep_targets.cpp"}
+
+
+def build_tools(force: bool = False, verbose: bool = False) -> None:
+    """The host executables (C++17, g++): `muscato` links libmuscato_hip.so by rpath."""
+    os.makedirs(BIN, exist_ok=True)
+    for name, src in TOOLS.items():
+        out = os.path.join(BIN, name)
+        srcp = os.path.join(HOST, src)
+        deps = [srcp] + HOST_HEADERS + HEADERS
+        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+            continue
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-o", out, srcp, "-lz"]
+        if name == "muscato":
+            cmd += ["-L" + HERE, "-lmuscato_hip", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    if force or needs_build():
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    build_tools(force=force, verbose=verbose)
     return LIB
 
 

@@ -1,0 +1,857 @@
+// Host side of the `muscato` drop-in: the reference's utils.Config / flag surface, read and
+// target preparation, and the text post-chain to results.txt -- everything around the GPU hot
+// path, which is reached only through the C ABI of include/muscato_hip.h.
+//
+// The reference host is compiled Go; no Go toolchain exists in this image, so the host is C++
+// (see INTEGRATION.md for the cgo binding a Go host would use instead).  Every function cites
+// the reference code whose behaviour it reproduces (paths relative to kshedden/muscato).
+#pragma once
+
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <random>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_set>
+#include <vector>
+
+#include "../../../include/muscato_hip.h"
+#include "sz.hpp"
+
+namespace musc {
+
+// ------------------------------------------------------------------------------------
+// utils.Config (utils/config.go:10-101) + the two additions of this build
+// ------------------------------------------------------------------------------------
+struct Config {
+  std::string ReadFileName, GeneFileName, GeneIdFileName, ResultsFileName;
+  std::vector<int> Windows;
+  int WindowWidth = 0;
+  uint64_t BloomSize = 0;
+  int NumHash = 0;
+  double PMatch = 0;
+  int MinDinuc = 0;
+  std::string TempDir, LogDir;
+  int MinReadLength = 0, MaxReadLength = 0, MaxMatches = 0, MaxConfirmProcs = 0, MMTol = 0;
+  std::string MatchMode;
+  int SortPar = 0;
+  std::string SortTemp, SortMem;
+  bool NoCleanTemp = false, CPUProfile = false;
+  // additions (not in the reference): absolute mismatch budget and GPU selection
+  int MaxMismatch = -1;  // --MaxMismatch: nmiss budget for every read instead of PMatch
+  int GPUs = 1;          // --GPUs: shard the unique reads over this many devices
+  int Device = 0;        // --Device: first device ordinal
+};
+
+struct Die : std::runtime_error {
+  int code;
+  Die(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// ---- minimal JSON reader for the flat config object (encoding/json semantics that matter:
+// case-insensitive keys, unknown keys ignored, null leaves the field untouched)
+struct JsonCursor {
+  const std::string& s;
+  size_t p = 0;
+  explicit JsonCursor(const std::string& t) : s(t) {}
+  void ws() { while (p < s.size() && isspace((unsigned char)s[p])) p++; }
+  bool eat(char c) { ws(); if (p < s.size() && s[p] == c) { p++; return true; } return false; }
+  void need(char c) { if (!eat(c)) throw Die(1, std::string("config: expected '") + c + "' at offset " + std::to_string(p)); }
+  std::string str() {
+    need('"');
+    std::string o;
+    while (p < s.size() && s[p] != '"') {
+      char c = s[p++];
+      if (c == '\\' && p < s.size()) {
+        char e = s[p++];
+        switch (e) {
+          case 'n': o += '\n'; break; case 't': o += '\t'; break; case 'r': o += '\r'; break;
+          case 'b': o += '\b'; break; case 'f': o += '\f'; break;
+          case 'u': { unsigned v = 0; for (int i = 0; i < 4 && p < s.size(); i++) v = v * 16 + (unsigned)strtol(std::string(1, s[p++]).c_str(), nullptr, 16);
+                      if (v < 0x80) o += (char)v; else if (v < 0x800) { o += (char)(0xC0 | (v >> 6)); o += (char)(0x80 | (v & 0x3F)); }
+                      else { o += (char)(0xE0 | (v >> 12)); o += (char)(0x80 | ((v >> 6) & 0x3F)); o += (char)(0x80 | (v & 0x3F)); } break; }
+          default: o += e;
+        }
+      } else {
+        o += c;
+      }
+    }
+    need('"');
+    return o;
+  }
+  std::string scalar() {  // number / true / false / null as text
+    ws();
+    size_t b = p;
+    while (p < s.size() && (isalnum((unsigned char)s[p]) || s[p] == '-' || s[p] == '+' || s[p] == '.')) p++;
+    return s.substr(b, p - b);
+  }
+};
+
+inline void config_from_json(const std::string& text, Config& c) {
+  JsonCursor j(text);
+  j.need('{');
+  if (j.eat('}')) return;
+  do {
+    const std::string key = to_lower(j.str());
+    j.need(':');
+    j.ws();
+    if (j.p < text.size() && text[j.p] == '"') {
+      const std::string v = j.str();
+      if (key == "readfilename") c.ReadFileName = v; else if (key == "genefilename") c.GeneFileName = v;
+      else if (key == "geneidfilename") c.GeneIdFileName = v; else if (key == "resultsfilename") c.ResultsFileName = v;
+      else if (key == "tempdir") c.TempDir = v; else if (key == "logdir") c.LogDir = v;
+      else if (key == "matchmode") c.MatchMode = v; else if (key == "sorttemp") c.SortTemp = v;
+      else if (key == "sortmem") c.SortMem = v;
+    } else if (j.p < text.size() && text[j.p] == '[') {
+      j.need('[');
+      std::vector<int> v;
+      if (!j.eat(']')) {
+        do { v.push_back(atoi(j.scalar().c_str())); } while (j.eat(','));
+        j.need(']');
+      }
+      if (key == "windows") c.Windows = v;
+    } else {
+      const std::string v = j.scalar();
+      if (v == "null" || v.empty()) continue;
+      const bool b = v == "true";
+      const double d = (v == "true" || v == "false") ? (double)b : atof(v.c_str());
+      if (key == "windowwidth") c.WindowWidth = (int)d; else if (key == "bloomsize") c.BloomSize = (uint64_t)d;
+      else if (key == "numhash") c.NumHash = (int)d; else if (key == "pmatch") c.PMatch = d;
+      else if (key == "mindinuc") c.MinDinuc = (int)d; else if (key == "minreadlength") c.MinReadLength = (int)d;
+      else if (key == "maxreadlength") c.MaxReadLength = (int)d; else if (key == "maxmatches") c.MaxMatches = (int)d;
+      else if (key == "maxconfirmprocs") c.MaxConfirmProcs = (int)d; else if (key == "mmtol") c.MMTol = (int)d;
+      else if (key == "sortpar") c.SortPar = (int)d; else if (key == "nocleantemp") c.NoCleanTemp = b;
+      else if (key == "cpuprofile") c.CPUProfile = b; else if (key == "maxmismatch") c.MaxMismatch = (int)d;
+      else if (key == "gpus") c.GPUs = (int)d; else if (key == "device") c.Device = (int)d;
+    }
+  } while (j.eat(','));
+  j.need('}');
+}
+
+inline std::string json_escape(const std::string& s) {
+  std::string o;
+  for (char c : s) {
+    if (c == '"' || c == '\\') { o += '\\'; o += c; }
+    else if (c == '\n') o += "\\n"; else if (c == '\t') o += "\\t";
+    else o += c;
+  }
+  return o;
+}
+
+// saveConfig (cmd/muscato/main.go:680-697): the resolved configuration, one JSON object
+inline std::string config_to_json(const Config& c) {
+  std::string w = "[";
+  for (size_t i = 0; i < c.Windows.size(); i++) w += (i ? "," : "") + std::to_string(c.Windows[i]);
+  w += "]";
+  char buf[64];
+  snprintf(buf, sizeof buf, "%.17g", c.PMatch);
+  auto S = [](const std::string& k, const std::string& v) { return "\"" + k + "\":\"" + json_escape(v) + "\""; };
+  auto N = [](const std::string& k, long long v) { return "\"" + k + "\":" + std::to_string(v); };
+  auto B = [](const std::string& k, bool v) { return "\"" + k + "\":" + (v ? "true" : "false"); };
+  return "{" + S("ReadFileName", c.ReadFileName) + "," + S("GeneFileName", c.GeneFileName) + "," +
+         S("GeneIdFileName", c.GeneIdFileName) + "," + S("ResultsFileName", c.ResultsFileName) + ",\"Windows\":" + w +
+         "," + N("WindowWidth", c.WindowWidth) + "," + N("BloomSize", (long long)c.BloomSize) + "," +
+         N("NumHash", c.NumHash) + ",\"PMatch\":" + buf + "," + N("MinDinuc", c.MinDinuc) + "," +
+         S("TempDir", c.TempDir) + "," + S("LogDir", c.LogDir) + "," + N("MinReadLength", c.MinReadLength) + "," +
+         N("MaxReadLength", c.MaxReadLength) + "," + N("MaxMatches", c.MaxMatches) + "," +
+         N("MaxConfirmProcs", c.MaxConfirmProcs) + "," + N("MMTol", c.MMTol) + "," + S("MatchMode", c.MatchMode) +
+         "," + N("SortPar", c.SortPar) + "," + S("SortTemp", c.SortTemp) + "," + S("SortMem", c.SortMem) + "," +
+         B("NoCleanTemp", c.NoCleanTemp) + "," + B("CPUProfile", c.CPUProfile) + "," +
+         N("MaxMismatch", c.MaxMismatch) + "," + N("GPUs", c.GPUs) + "," + N("Device", c.Device) + "}\n";
+}
+
+// ---- Go `flag` syntax: -name, --name, -name=value, -name value; bools take no value unless
+// written -name=value; parsing stops at the first non-flag or at "--".
+struct FlagSpec { const char* name; char kind; const char* help; };  // kind: s i f b
+
+inline const std::vector<FlagSpec>& muscato_flags() {
+  // cmd/muscato/main.go:708-732 (same names, kinds and help strings) + the additions
+  static const std::vector<FlagSpec> f = {
+      {"ConfigFileName", 's', "JSON file containing configuration parameters"},
+      {"ReadFileName", 's', "Sequencing read file (fastq format)"},
+      {"GeneFileName", 's', "Gene file name (processed form)"},
+      {"GeneIdFileName", 's', "Gene ID file name (processed form)"},
+      {"ResultsFileName", 's', "File name for results"},
+      {"Windows", 's', "Starting position of each window"},
+      {"WindowWidth", 'i', "Width of each window"},
+      {"BloomSize", 'i', "Size of Bloom filter, in bits"},
+      {"NumHash", 'i', "Number of hashses"},
+      {"PMatch", 'f', "Required proportion of matching positions"},
+      {"MinDinuc", 'i', "Minimum number of dinucleotides to check for match"},
+      {"TempDir", 's', "Workspace for temporary files"},
+      {"MinReadLength", 'i', "Reads shorter than this length are skipped"},
+      {"MaxReadLength", 'i', "Reads longer than this length are truncated"},
+      {"MaxMatches", 'i', "Return no more than this number of matches per window"},
+      {"MaxConfirmProcs", 'i', "Run this number of match confirmation processes concurrently"},
+      {"MMTol", 'i', "Number of mismatches allowed above best fit"},
+      {"MatchMode", 's', "'first' or 'best' (retain first/best 'MaxMatches' matches meeting criteria)"},
+      {"NoCleanTemp", 'b', "Do not delete temporary files from TempDir"},
+      {"SortPar", 'i', "Number of parallel sort processes"},
+      {"SortTemp", 's', "Directory to use for sort temp files"},
+      {"SortMem", 's', "Gnu sort -S parameter"},
+      {"CPUProfile", 'b', "Capture CPU profile data"},
+      {"MaxMismatch", 'i', "(addition) absolute mismatch budget per read; overrides PMatch when >= 0"},
+      {"GPUs", 'i', "(addition) number of GPUs to shard the reads over"},
+      {"Device", 'i', "(addition) first GPU ordinal"},
+  };
+  return f;
+}
+
+inline std::string usage(const char* prog, const std::vector<FlagSpec>& flags) {
+  std::vector<FlagSpec> v = flags;
+  std::sort(v.begin(), v.end(), [](const FlagSpec& a, const FlagSpec& b) { return strcmp(a.name, b.name) < 0; });
+  std::string o = std::string("Usage of ") + prog + ":\n";
+  for (auto& f : v) {
+    const char* ty = f.kind == 's' ? " string" : f.kind == 'i' ? " int" : f.kind == 'f' ? " float" : "";
+    o += std::string("  -") + f.name + ty + "\n    \t" + f.help + "\n";
+  }
+  return o;
+}
+
+// returns name -> value for the flags present; bools map to "true"/"false"
+inline std::map<std::string, std::string> parse_flags(int argc, char** argv, const std::vector<FlagSpec>& flags,
+                                                      std::vector<std::string>* rest) {
+  std::map<std::string, std::string> out;
+  int i = 1;
+  for (; i < argc; i++) {
+    std::string a = argv[i];
+    if (a.size() < 2 || a[0] != '-') break;
+    if (a == "--") { i++; break; }
+    size_t b = a[1] == '-' ? 2 : 1;
+    std::string name = a.substr(b), val;
+    bool hasval = false;
+    size_t eq = name.find('=');
+    if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); hasval = true; }
+    if (name == "help" || name == "h") throw Die(0, usage(argv[0], flags));
+    const FlagSpec* spec = nullptr;
+    for (auto& f : flags) if (name == f.name) spec = &f;
+    if (!spec) throw Die(2, "flag provided but not defined: -" + name + "\n" + usage(argv[0], flags));
+    if (spec->kind == 'b') {
+      if (!hasval) val = "true";
+      if (val != "true" && val != "false" && val != "1" && val != "0" && val != "t" && val != "f" && val != "T" &&
+          val != "F" && val != "TRUE" && val != "FALSE" && val != "True" && val != "False")
+        throw Die(2, "invalid boolean value \"" + val + "\" for -" + name);
+      val = (val[0] == 't' || val[0] == 'T' || val[0] == '1') ? "true" : "false";
+    } else {
+      if (!hasval) {
+        if (i + 1 >= argc) throw Die(2, "flag needs an argument: -" + name);
+        val = argv[++i];
+      }
+      if (spec->kind == 'i') {
+        char* e = nullptr;
+        strtoll(val.c_str(), &e, 0);
+        if (val.empty() || *e) throw Die(2, "invalid value \"" + val + "\" for flag -" + name + ": parse error");
+      } else if (spec->kind == 'f') {
+        char* e = nullptr;
+        strtod(val.c_str(), &e);
+        if (val.empty() || *e) throw Die(2, "invalid value \"" + val + "\" for flag -" + name + ": parse error");
+      }
+    }
+    out[name] = val;
+  }
+  if (rest) for (; i < argc; i++) rest->push_back(argv[i]);
+  return out;
+}
+
+// handleArgs (cmd/muscato/main.go:708-831): JSON first, then every non-zero flag overrides
+inline Config handle_args(int argc, char** argv) {
+  auto fl = parse_flags(argc, argv, muscato_flags(), nullptr);
+  Config c;
+  auto has = [&](const char* k) { return fl.count(k) > 0; };
+  auto I = [&](const char* k) { return (int)strtoll(fl[k].c_str(), nullptr, 0); };
+  if (has("ConfigFileName") && !fl["ConfigFileName"].empty()) config_from_json(slurp(fl["ConfigFileName"]), c);
+  if (has("ReadFileName") && !fl["ReadFileName"].empty()) c.ReadFileName = fl["ReadFileName"];
+  if (has("GeneFileName") && !fl["GeneFileName"].empty()) c.GeneFileName = fl["GeneFileName"];
+  if (has("GeneIdFileName") && !fl["GeneIdFileName"].empty()) c.GeneIdFileName = fl["GeneIdFileName"];
+  if (has("WindowWidth") && I("WindowWidth")) c.WindowWidth = I("WindowWidth");
+  if (has("BloomSize") && I("BloomSize")) c.BloomSize = (uint64_t)strtoll(fl["BloomSize"].c_str(), nullptr, 0);
+  if (has("NumHash") && I("NumHash")) c.NumHash = I("NumHash");
+  if (has("PMatch") && atof(fl["PMatch"].c_str()) != 0) c.PMatch = atof(fl["PMatch"].c_str());
+  if (has("MinDinuc") && I("MinDinuc")) c.MinDinuc = I("MinDinuc");
+  if (has("TempDir") && !fl["TempDir"].empty()) c.TempDir = fl["TempDir"];
+  if (has("MinReadLength") && I("MinReadLength")) c.MinReadLength = I("MinReadLength");
+  if (has("MaxReadLength") && I("MaxReadLength")) c.MaxReadLength = I("MaxReadLength");
+  if (has("MaxMatches") && I("MaxMatches")) c.MaxMatches = I("MaxMatches");
+  if (has("MaxConfirmProcs") && I("MaxConfirmProcs")) c.MaxConfirmProcs = I("MaxConfirmProcs");
+  if (has("MatchMode") && !fl["MatchMode"].empty()) c.MatchMode = fl["MatchMode"];
+  if (has("MMTol") && I("MMTol")) c.MMTol = I("MMTol");
+  if (has("ResultsFileName") && !fl["ResultsFileName"].empty()) c.ResultsFileName = fl["ResultsFileName"];
+  if (has("NoCleanTemp") && fl["NoCleanTemp"] == "true") c.NoCleanTemp = true;
+  if (has("CPUProfile") && fl["CPUProfile"] == "true") c.CPUProfile = true;
+  if (has("SortPar") && I("SortPar")) c.SortPar = I("SortPar");
+  if (has("SortMem") && !fl["SortMem"].empty()) c.SortMem = fl["SortMem"];
+  if (has("SortTemp") && !fl["SortTemp"].empty()) c.SortTemp = fl["SortTemp"];
+  if (has("MaxMismatch")) c.MaxMismatch = I("MaxMismatch");
+  if (has("GPUs") && I("GPUs")) c.GPUs = I("GPUs");
+  if (has("Device")) c.Device = I("Device");
+  if (c.ResultsFileName.empty()) {
+    c.ResultsFileName = "results.txt";
+    fputs("ResultsFileName not specified, defaulting to 'results.txt'\n", stderr);
+  }
+  if (has("Windows") && !fl["Windows"].empty()) {
+    c.Windows.clear();
+    std::string w = fl["Windows"];
+    size_t p = 0;
+    while (p <= w.size()) {
+      size_t e = w.find(',', p);
+      std::string tok = w.substr(p, e == std::string::npos ? std::string::npos : e - p);
+      char* end = nullptr;
+      long v = strtol(tok.c_str(), &end, 10);
+      if (tok.empty() || *end) throw Die(1, "Error in handleArgs: bad Windows value \"" + tok + "\"");
+      c.Windows.push_back((int)v);
+      if (e == std::string::npos) break;
+      p = e + 1;
+    }
+  }
+  return c;
+}
+
+// checkArgs (cmd/muscato/main.go:833-904): required fields and defaults, same messages
+inline void check_args(Config& c) {
+  auto need = [](bool ok, const char* what) {
+    if (!ok) throw Die(1, std::string("\n") + what + " not provided, run 'muscato --help for more information.\n\n");
+  };
+  need(!c.ReadFileName.empty(), "ReadFileName");
+  need(!c.GeneFileName.empty(), "GeneFileName");
+  need(!c.GeneIdFileName.empty(), "GeneIdFileName");
+  need(!c.Windows.empty(), "Windows");
+  need(c.WindowWidth != 0, "WindowWidth");
+  if (c.BloomSize == 0) { fputs("BloomSize not provided, defaulting to 4 billion\n", stderr); c.BloomSize = 4000000000ull; }
+  if (c.NumHash == 0) { fputs("NumHash not provided, defaulting to 20\n", stderr); c.NumHash = 20; }
+  if (c.PMatch == 0) { fputs("PMatch not provided, defaulting to 1\n", stderr); c.PMatch = 1; }
+  if (c.MaxReadLength == 0) throw Die(1, "MaxReadLength not provided, run 'muscato --help for more information.\n\n");
+  if (c.MaxMatches == 0) { fputs("MaxMatches not provided, defaulting to 1 million\n", stderr); c.MaxMatches = 1000000; }
+  if (c.MaxConfirmProcs == 0) { fputs("MaxConfirmProcs not provided, defaulting to 3\n", stderr); c.MaxConfirmProcs = 3; }
+  if (!ends_with(c.ReadFileName, ".fastq"))
+    fprintf(stderr, "Warning: %s may not be a fastq file, continuing anyway\n", c.ReadFileName.c_str());
+  if (c.MatchMode.empty()) { fputs("MatchMode not provided, defaulting to 'best'\n", stderr); c.MatchMode = "best"; }
+  if (c.MatchMode != "best" && c.MatchMode != "first") throw Die(1, "MatchMode must be 'first' or 'best'\n");
+  if (c.SortPar == 0) c.SortPar = 8;
+  if (c.SortMem.empty()) { fputs("SortMem not provided, defaulting to 50%\n", stderr); c.SortMem = "50%"; }
+  if ((int)c.Windows.size() > MUSC_MAX_WINDOWS)
+    throw Die(1, "at most " + std::to_string(MUSC_MAX_WINDOWS) + " windows are supported by this build\n");
+  if (c.GPUs < 1) c.GPUs = 1;
+}
+
+// ------------------------------------------------------------------------------------
+// target preparation (cmd/muscato_prep_targets/main.go)
+// ------------------------------------------------------------------------------------
+inline void subx(std::string& s) {  // :68-80 and cmd/muscato_prep_reads/main.go:33-44
+  for (auto& c : s) if (c != 'A' && c != 'T' && c != 'C' && c != 'G') c = 'X';
+}
+
+inline std::string revcomp(const std::string& s) {  // :48-66 (bytes outside ATGCX become 0)
+  std::string b(s.size(), '\0');
+  const size_t m = s.size();
+  for (size_t i = 0; i < m; i++) {
+    char o = 0;
+    switch (s[i]) { case 'A': o = 'T'; break; case 'T': o = 'A'; break; case 'G': o = 'C'; break;
+                    case 'C': o = 'G'; break; case 'X': o = 'X'; break; }
+    b[m - 1 - i] = o;
+  }
+  return b;
+}
+
+struct PreparedTargets {
+  std::vector<std::string> seqs;  // one line each of musc_<file>.sz
+  std::vector<std::string> ids;   // "%011d\tname\tlen" lines of musc_ids_<file>.sz
+};
+
+inline std::string id_line(size_t num, const std::string& name, size_t len) {
+  char b[32];
+  snprintf(b, sizeof b, "%011zu", num);
+  return std::string(b) + "\t" + name + "\t" + std::to_string(len);
+}
+
+inline PreparedTargets prep_targets_text(const std::string& raw, bool rev) {  // processText :82-141
+  PreparedTargets out;
+  size_t lnum = 0;
+  for (auto& line : split_lines(raw)) {
+    if (line.empty()) break;
+    size_t t = line.find('\t');
+    if (t == std::string::npos || line.find('\t', t + 1) != std::string::npos) break;  // reference logs + exit(0)
+    std::string nam = line.substr(0, t), seq = line.substr(t + 1);
+    subx(seq);
+    out.seqs.push_back(seq);
+    if (rev) out.seqs.push_back(revcomp(seq));
+    out.ids.push_back(id_line(lnum++, nam, seq.size()));
+    if (rev) out.ids.push_back(id_line(lnum++, nam + "_r", seq.size()));
+  }
+  return out;
+}
+
+inline PreparedTargets prep_targets_fasta(const std::string& raw, bool rev) {  // processFasta :143-213
+  PreparedTargets out;
+  std::string name, seq;
+  auto flush = [&](const std::string& s, bool r) {
+    out.seqs.push_back(s);
+    out.ids.push_back(id_line(out.ids.size(), name + (r ? "_r" : ""), s.size()));
+  };
+  for (auto& line : split_lines(raw)) {
+    if (line.empty()) throw Die(1, "muscato_prep_targets: empty line in FASTA input (the reference panics here)");
+    if (line[0] == '>') {
+      if (!seq.empty()) {
+        subx(seq);
+        flush(seq, false);
+        if (rev) flush(revcomp(seq), true);
+      }
+      name = line;  // the leading '>' is kept (:199)
+      seq.clear();
+      continue;
+    }
+    seq += line;
+  }
+  if (!seq.empty()) {  // the last record is NOT subx-ed (:204-212)
+    flush(seq, false);
+    if (rev) flush(revcomp(seq), true);
+  }
+  return out;
+}
+
+// targets() + main (:215-333): .gz/.sz inputs, "fasta" decided on the original file name,
+// outputs musc_<file>.sz and musc_ids_<file>.sz next to the input
+inline void prep_targets_file(const std::string& path, bool rev, std::string* seq_out, std::string* id_out) {
+  const std::string low = to_lower(path);
+  std::string raw;
+  if (ends_with(low, ".gz")) raw = gz_decode_file(path);
+  else if (ends_with(low, ".sz")) raw = sz_decode(slurp(path));
+  else raw = slurp(path);
+  PreparedTargets pt = ends_with(low, "fasta") ? prep_targets_fasta(raw, rev) : prep_targets_text(raw, rev);
+  size_t slash = path.rfind('/');
+  std::string dir = slash == std::string::npos ? "" : path.substr(0, slash + 1);
+  std::string file = slash == std::string::npos ? path : path.substr(slash + 1);
+  std::string lowf = to_lower(file);
+  if (ends_with(lowf, ".gz") || ends_with(lowf, ".sz")) file = file.substr(0, file.size() - 3);
+  *seq_out = dir + "musc_" + file + ".sz";
+  *id_out = dir + "musc_ids_" + file + ".sz";
+  std::string a, b;
+  for (auto& s : pt.seqs) { a += s; a += '\n'; }
+  for (auto& s : pt.ids) { b += s; b += '\n'; }
+  spit(*seq_out, sz_encode(a));
+  spit(*id_out, sz_encode(b));
+}
+
+// ------------------------------------------------------------------------------------
+// read preparation: utils/fastq.go, cmd/muscato_prep_reads, `sort`, cmd/muscato_uniqify
+// ------------------------------------------------------------------------------------
+struct UniqueRead {
+  std::string seq;
+  size_t count;
+  std::string names;
+};
+
+inline std::vector<UniqueRead> prep_reads(const std::string& fastq, const Config& c, size_t* n_total) {
+  const std::vector<std::string> lines = split_lines(fastq);
+  std::vector<std::string> recs;  // "seq\tname"
+  for (size_t i = 0; i + 4 <= lines.size(); i += 4) {
+    // utils/fastq.go:35-61: 4 lines per record, name = whole first line; an incomplete
+    // trailing record is dropped
+    const std::string& name = lines[i];
+    std::string seq = lines[i + 1];
+    if ((int)seq.size() < c.MinReadLength) continue;           // cmd/muscato_prep_reads/main.go:59-62 (raw length)
+    subx(seq);                                                 // :64-65
+    if ((int)seq.size() > c.MaxReadLength) seq.resize(c.MaxReadLength);  // :67-69
+    std::string rn = name;
+    if (rn.size() > 1000) rn = rn.substr(0, 995) + "...";      // :76-79
+    recs.push_back(seq + "\t" + rn);
+  }
+  std::sort(recs.begin(), recs.end());  // LC_ALL=C sort of whole lines (cmd/muscato/main.go:180-189)
+  if (n_total) *n_total = recs.size();
+  // cmd/muscato_uniqify/main.go:83-135
+  std::vector<UniqueRead> out;
+  std::vector<std::string> names;
+  std::string cur;
+  bool have = false;
+  auto flush = [&]() {
+    std::string na;
+    for (size_t i = 0; i < names.size(); i++) { if (i) na += ';'; na += names[i]; }
+    if (na.size() > 1000) na = na.substr(0, 996) + "...";
+    out.push_back(UniqueRead{cur, names.size(), na});
+  };
+  for (auto& r : recs) {
+    size_t t = r.find('\t');
+    std::string seq = r.substr(0, t);
+    size_t t2 = r.find('\t', t + 1);
+    std::string nm = r.substr(t + 1, t2 == std::string::npos ? std::string::npos : t2 - t - 1);
+    if (!have || seq != cur) {
+      if (have) flush();
+      cur = seq;
+      names.clear();
+      have = true;
+    }
+    names.push_back(nm);
+  }
+  if (have) flush();
+  return out;
+}
+
+// ------------------------------------------------------------------------------------
+// post-chain (cmd/muscato/main.go:422-676) and side outputs
+// ------------------------------------------------------------------------------------
+
+// Go's strings.Fields / bytes.Fields on ASCII whitespace
+inline std::vector<std::string> fields(const std::string& s) {
+  std::vector<std::string> f;
+  size_t i = 0;
+  while (i < s.size()) {
+    while (i < s.size() && isspace((unsigned char)s[i])) i++;
+    size_t b = i;
+    while (i < s.size() && !isspace((unsigned char)s[i])) i++;
+    if (i > b) f.emplace_back(s, b, i - b);
+  }
+  return f;
+}
+
+// hits must already be the per-read best+MMTol selection (matches.txt).  Produces the bytes
+// of ResultsFileName: sort -k5 + join with the id file + cut (:524-611) turns the gene number
+// into "name\tlen" (hits whose number is absent from the id file are unpairable and vanish);
+// sort -k1 (:657) orders the six-column lines bytewise; join (:659) appends count and names.
+inline std::string results_text(const musc_hit* hits, size_t nhits, const std::vector<UniqueRead>& reads,
+                                const std::vector<std::string>& targets,
+                                const std::map<uint64_t, std::string>& id_rest) {
+  struct Line { std::string six; uint32_t read; };
+  std::vector<Line> lines;
+  lines.reserve(nhits);
+  for (size_t i = 0; i < nhits; i++) {
+    const musc_hit& h = hits[i];
+    auto it = id_rest.find(h.gene_idx);
+    if (it == id_rest.end()) continue;
+    const std::string& r = reads[h.read_idx].seq;
+    std::string six = r;
+    six += '\t';
+    six.append(targets[h.gene_idx], h.pos, r.size());
+    six += '\t';
+    six += std::to_string(h.pos);
+    six += '\t';
+    six += std::to_string(h.nmiss);
+    six += '\t';
+    six += it->second;
+    lines.push_back(Line{std::move(six), h.read_idx});
+  }
+  std::sort(lines.begin(), lines.end(), [](const Line& a, const Line& b) { return a.six < b.six; });
+  std::string out;
+  for (auto& l : lines) {
+    out += l.six;
+    out += '\t';
+    out += std::to_string(reads[l.read].count);
+    out += '\t';
+    out += reads[l.read].names;
+    out += '\n';
+  }
+  return out;
+}
+
+inline std::string nonmatch_name(const std::string& results) {  // cmd/muscato_nonmatch/main.go:67-73
+  size_t slash = results.rfind('/');
+  std::string a = slash == std::string::npos ? "" : results.substr(0, slash + 1);
+  std::string b = slash == std::string::npos ? results : results.substr(slash + 1);
+  std::vector<std::string> c;
+  size_t p = 0;
+  for (;;) {
+    size_t e = b.find('.', p);
+    c.push_back(b.substr(p, e == std::string::npos ? std::string::npos : e - p));
+    if (e == std::string::npos) break;
+    p = e + 1;
+  }
+  std::string d = c.back();
+  c.back() = "nonmatch";
+  c.push_back(d + ".fastq");
+  std::string j;
+  for (size_t i = 0; i < c.size(); i++) { if (i) j += '.'; j += c[i]; }
+  return a + j;
+}
+
+// cmd/muscato_nonmatch/main.go:95-114 with an exact set in place of the Bloom filter
+inline std::string nonmatch_text(const std::string& results, const std::vector<UniqueRead>& reads) {
+  std::unordered_set<std::string> matched;
+  for (auto& line : split_lines(results)) {
+    auto f = fields(line);
+    if (!f.empty()) matched.insert(f[0]);
+  }
+  std::string out;
+  for (auto& u : reads) {
+    if (matched.count(u.seq)) continue;
+    auto f = fields(u.seq + "\t" + std::to_string(u.count) + "\t" + u.names);
+    if (f.size() < 3) continue;  // the reference would panic on an empty name
+    out += f[2] + "#" + f[1] + "\n" + f[0] + "\n+\n" + std::string(f[0].size(), '!') + "\n";
+  }
+  return out;
+}
+
+inline std::string stats_name(const std::string& results, const char* tag) {  // path.Ext handling, :113-120
+  size_t slash = results.rfind('/');
+  size_t dot = results.rfind('.');
+  if (dot != std::string::npos && (slash == std::string::npos || dot > slash))
+    return results.substr(0, dot) + tag + results.substr(dot);
+  return results + tag;
+}
+
+// cmd/muscato/main.go:94-150 + cmd/muscato_genestats/main.go: sort -k5, count runs of column 5
+inline std::string genestats_text(const std::string& results) {
+  std::vector<std::string> lines = split_lines(results);
+  auto key5 = [](const std::string& l) {  // GNU sort -k5: from the blank before field 5 to the end
+    size_t p = 0;
+    for (int f = 0; f < 4; f++) {
+      while (p < l.size() && (l[p] == ' ' || l[p] == '\t')) p++;
+      while (p < l.size() && l[p] != ' ' && l[p] != '\t') p++;
+    }
+    return l.substr(p);
+  };
+  std::sort(lines.begin(), lines.end(), [&](const std::string& a, const std::string& b) {
+    const std::string ka = key5(a), kb = key5(b);
+    if (ka != kb) return ka < kb;
+    return a < b;
+  });
+  std::string out, old;
+  size_t n = 0;
+  bool first = true;
+  for (auto& l : lines) {
+    auto f = fields(l);
+    if (f.size() < 5) continue;
+    if (first) { old = f[4]; first = false; }
+    if (f[4] != old) { out += old + "\t" + std::to_string(n) + "\t\n"; old = f[4]; n = 0; }
+    n++;
+  }
+  if (!first) out += old + "\t" + std::to_string(n) + "\t\n";
+  return out;
+}
+
+// cmd/muscato_readstats/main.go: per run of equal names-column tokens, the set of gene names.
+// The reference prints the set in Go map order (random); here it is sorted.
+inline std::string readstats_text(const std::string& results) {
+  std::string out, old;
+  std::set<std::string> genes;
+  bool first = true;
+  auto flush = [&]() {
+    out += old + "\t";
+    for (auto& g : genes) out += g + ";";
+    out += "\n";
+  };
+  for (auto& l : split_lines(results)) {
+    auto f = fields(l);
+    if (f.size() < 8) continue;
+    if (first) { old = f[7]; first = false; }
+    if (f[7] != old) { flush(); old = f[7]; genes.clear(); }
+    genes.insert(f[4]);
+  }
+  if (!first) flush();
+  return out;
+}
+
+// ------------------------------------------------------------------------------------
+// the pipeline (cmd/muscato/main.go:1005-1058), hot path through the C ABI
+// ------------------------------------------------------------------------------------
+inline void mkdir_p(const std::string& path) {
+  std::string cur;
+  for (size_t i = 0; i <= path.size(); i++) {
+    if (i == path.size() || path[i] == '/') {
+      if (!cur.empty() && mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST)
+        throw Die(1, "Directory " + cur + " does not exist and cannot be created.");
+    }
+    if (i < path.size()) cur += path[i];
+  }
+}
+
+inline std::string join_path(const std::string& a, const std::string& b) {
+  if (a.empty()) return b;
+  return a.back() == '/' ? a + b : a + "/" + b;
+}
+
+inline std::string make_uid() {  // stands in for uuid.NewUUID (cmd/muscato/main.go:933)
+  std::random_device rd;
+  char b[40];
+  snprintf(b, sizeof b, "%08x-%04x-%04x-%04x-%08x%04x", (unsigned)rd(), (unsigned)rd() & 0xFFFF, (unsigned)rd() & 0xFFFF,
+           (unsigned)rd() & 0xFFFF, (unsigned)rd(), (unsigned)rd() & 0xFFFF);
+  return b;
+}
+
+struct Logger {
+  FILE* f = nullptr;
+  void open(const std::string& path) { f = fopen(path.c_str(), "w"); }
+  void printf(const char* fmt, ...) {
+    if (!f) return;
+    time_t t = time(nullptr);
+    struct tm tmv;
+    localtime_r(&t, &tmv);
+    fprintf(f, "%02d:%02d:%02d ", tmv.tm_hour, tmv.tm_min, tmv.tm_sec);
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(f, fmt, ap);
+    va_end(ap);
+    fputc('\n', f);
+    fflush(f);
+  }
+  ~Logger() { if (f) fclose(f); }
+};
+
+inline musc_params to_params(const Config& c) {
+  musc_params p;
+  memset(&p, 0, sizeof p);
+  p.n_windows = (int)c.Windows.size();
+  for (int i = 0; i < p.n_windows; i++) p.windows[i] = c.Windows[i];
+  p.window_width = c.WindowWidth;
+  p.pmatch = c.PMatch;
+  p.min_dinuc = c.MinDinuc;
+  p.max_read_length = c.MaxReadLength;
+  p.max_matches = c.MaxMatches;
+  p.match_mode = c.MatchMode == "first" ? 1 : 0;
+  p.mmtol = c.MMTol;
+  p.apply_mmtol = 1;
+  p.max_mismatch_p1 = c.MaxMismatch >= 0 ? c.MaxMismatch + 1 : 0;
+  return p;
+}
+
+struct Concat {
+  std::string buf;
+  std::vector<uint64_t> off;
+};
+
+template <class It, class F>
+inline Concat concat(It b, It e, F seq_of) {
+  Concat c;
+  c.off.push_back(0);
+  for (It i = b; i != e; ++i) {
+    c.buf += seq_of(*i);
+    c.off.push_back(c.buf.size());
+  }
+  c.buf.append(16, '\0');
+  return c;
+}
+
+// Load the targets, shard the unique reads over cfg.GPUs devices (one host thread + one
+// musc_ctx per device, as the ABI's threading rule asks), run the hot path, gather.
+inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<UniqueRead>& reads,
+                                          const std::vector<std::string>& targets, Logger& log, musc_stats* stats0) {
+  const int G = cfg.GPUs;
+  const Concat db = concat(targets.begin(), targets.end(), [](const std::string& s) -> const std::string& { return s; });
+  if (targets.size() >= 0xFFFFFFFFull) throw Die(1, "too many targets");
+  std::vector<musc_ctx*> ctxs(G, nullptr);
+  std::vector<uint64_t> base(G, 0);
+  std::vector<std::string> errs(G);
+  const musc_params P = to_params(cfg);
+  std::vector<std::thread> th;
+  for (int g = 0; g < G; g++) {
+    const size_t lo = reads.size() * (size_t)g / G, hi = reads.size() * (size_t)(g + 1) / G;
+    base[g] = lo;
+    th.emplace_back([&, g, lo, hi] {
+      musc_ctx* c = nullptr;
+      if (musc_init(cfg.Device + g, &c)) { errs[g] = musc_last_error(nullptr); return; }
+      ctxs[g] = c;
+      const Concat rd = concat(reads.begin() + lo, reads.begin() + hi, [](const UniqueRead& u) -> const std::string& { return u.seq; });
+      uint64_t n = 0;
+      if (musc_db_load_ascii(c, db.buf.data(), db.off.data(), (uint32_t)targets.size(), 0) ||
+          musc_reads_load_ascii(c, rd.buf.data(), rd.off.data(), hi - lo, 0) || musc_match_device(c, &P, &n))
+        errs[g] = musc_last_error(c);
+    });
+  }
+  for (auto& t : th) t.join();
+  std::string err;
+  for (int g = 0; g < G; g++) if (!errs[g].empty()) err += "GPU " + std::to_string(cfg.Device + g) + ": " + errs[g] + "\n";
+  std::vector<musc_hit> out;
+  if (err.empty()) {
+    musc_hit* h = nullptr;
+    uint64_t n = 0;
+    if (musc_gather(ctxs.data(), G, base.data(), &h, &n)) err = musc_last_error(ctxs[0]);
+    else {
+      out.assign(h, h + n);
+      musc_free_hits(h);
+    }
+    if (stats0) musc_get_stats(ctxs[0], stats0);
+    for (int g = 0; g < G; g++) {
+      musc_stats s;
+      musc_get_stats(ctxs[g], &s);
+      log.printf("gpu %d: reads %llu windows %llu candidates %llu pairs %llu accepted %llu hits %llu; device %.3f ms "
+                 "(seed %.3f scan %.3f expand %.3f confirm %.3f select %.3f), index build %.1f ms, confirm %.1f GB/s",
+                 cfg.Device + g, (unsigned long long)s.n_reads, (unsigned long long)s.n_read_windows,
+                 (unsigned long long)s.n_candidates, (unsigned long long)s.n_pairs, (unsigned long long)s.n_accepted,
+                 (unsigned long long)s.n_hits, s.ms_total, s.ms_seed, s.ms_scan, s.ms_expand, s.ms_confirm, s.ms_select,
+                 s.ms_index_build, s.ms_confirm > 0 ? s.confirm_bytes / 1e6 / s.ms_confirm : 0.0);
+    }
+  }
+  for (auto c : ctxs) if (c) musc_destroy(c);
+  if (!err.empty()) throw Die(1, "muscato hot path failed:\n" + err);
+  return out;
+}
+
+inline int run_muscato(Config cfg) {
+  // setupEnvs/makeTemp/setupLog/saveConfig (cmd/muscato/main.go:906-967, 680-706)
+  const std::string uid = make_uid();
+  cfg.TempDir = join_path(cfg.TempDir.empty() ? "muscato_tmp" : cfg.TempDir, uid);
+  mkdir_p(cfg.TempDir);
+  cfg.LogDir = join_path(cfg.LogDir.empty() ? "muscato_logs" : cfg.LogDir, uid);
+  mkdir_p(cfg.LogDir);
+  Logger log;
+  log.open(join_path(cfg.LogDir, "muscato.log"));
+  spit(join_path(cfg.LogDir, "config.json"), config_to_json(cfg));
+
+  fputs("Preparing reads...\n", stderr);
+  size_t n_total = 0;
+  std::vector<UniqueRead> reads = prep_reads(slurp(cfg.ReadFileName), cfg, &n_total);
+  if (reads.empty()) throw Die(1, "muscato_uniqify: no input from -");
+  fprintf(stderr, "Found %zu total sequences\nFound %zu unique sequences\n", n_total, reads.size());
+  spit(join_path(cfg.LogDir, "seqinfo.json"),
+       "{\"NumUnique\":" + std::to_string(reads.size()) + ",\"NumTotal\":" + std::to_string(n_total) + "}\n");
+  if (cfg.NoCleanTemp) {  // keep the one intermediate other tools consume
+    std::string t;
+    for (auto& u : reads) t += u.seq + "\t" + std::to_string(u.count) + "\t" + u.names + "\n";
+    spit(join_path(cfg.TempDir, "reads_sorted.txt.sz"), sz_encode(t));
+  }
+
+  fputs("Windowing reads...\n", stderr);
+  for (size_t k = 0; k < cfg.Windows.size(); k++) {  // cmd/muscato_window_reads/main.go:143-151
+    size_t nvalid = 0;
+    for (auto& u : reads) nvalid += (int)u.seq.size() >= cfg.Windows[k] + cfg.WindowWidth;
+    log.printf("Window %zu produced %zu valid reads", k, nvalid);
+    if (nvalid == 0) throw Die(1, "Window " + std::to_string(k) + " produced no valid reads, exiting");
+  }
+
+  // gene file: sequence = text before the first tab, gene number = line index
+  // (cmd/muscato_screen/main.go:439-452); id file: "%011d\tname\tlen" (join field 1)
+  std::vector<std::string> targets;
+  for (auto& l : split_lines(read_maybe_sz(cfg.GeneFileName))) targets.push_back(l.substr(0, l.find('\t')));
+  std::map<uint64_t, std::string> id_rest;
+  for (auto& l : split_lines(read_maybe_sz(cfg.GeneIdFileName))) {
+    size_t t = l.find('\t');
+    if (t == std::string::npos) continue;
+    id_rest.emplace(strtoull(l.substr(0, t).c_str(), nullptr, 10), l.substr(t + 1));
+  }
+
+  fputs("Screening...\nConfirming...\n", stderr);
+  musc_stats st;
+  memset(&st, 0, sizeof st);
+  std::vector<musc_hit> hits = run_hot_path(cfg, reads, targets, log, &st);
+  if (st.n_overflow_blocks)
+    fprintf(stderr, "Warning: %llu window-key blocks may exceed MaxMatches; results keep all their matches\n",
+            (unsigned long long)st.n_overflow_blocks);
+
+  fputs("Combining windows...\nJoining gene names...\nJoining read names...\n", stderr);
+  const std::string res = results_text(hits.data(), hits.size(), reads, targets, id_rest);
+  spit(cfg.ResultsFileName, res);
+
+  fputs("Writing non-matching sequences...\n", stderr);
+  spit(nonmatch_name(cfg.ResultsFileName), nonmatch_text(res, reads));
+  fputs("Generating read statistics...\n", stderr);
+  spit(stats_name(cfg.ResultsFileName, "_readstats"), readstats_text(res));
+  fputs("Generating gene statistics...\n", stderr);
+  spit(stats_name(cfg.ResultsFileName, "_genestats"), genestats_text(res));
+
+  if (!cfg.NoCleanTemp) {  // cleanTmp (cmd/muscato/main.go:969-979)
+    unlink(join_path(cfg.TempDir, "reads_sorted.txt.sz").c_str());
+    rmdir(cfg.TempDir.c_str());
+  }
+  return 0;
+}
+
+}  // namespace musc

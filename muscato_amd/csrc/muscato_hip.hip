@@ -940,6 +940,7 @@ int check_params(musc_ctx* c, const musc_params* P) {
   if (!(P->pmatch >= 0.0 && P->pmatch <= 1.0)) return fail(c, 2, "PMatch=%g outside [0,1]", P->pmatch);
   if (P->match_mode != 0 && P->match_mode != 1) return fail(c, 2, "match_mode must be 0 (best) or 1 (first)");
   if (P->mmtol < 0) return fail(c, 2, "MMTol < 0");
+  if (P->max_mismatch_p1 < 0) return fail(c, 2, "max_mismatch_p1 < 0");
   return 0;
 }
 
@@ -1324,6 +1325,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       volatile double a = 1.0 - P->pmatch;
       volatile double b = a * (double)L;
       long long v = (long long)b;
+      if (P->max_mismatch_p1 > 0) v = P->max_mismatch_p1 - 1;  // --MaxMismatch addition
       if (v < 0) v = 0;
       if (v > 0xFFFE) v = 0xFFFE;
       tab[L] = (uint16_t)v;
