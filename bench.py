@@ -94,6 +94,7 @@ def main() -> int:
     ap.add_argument("--reads", type=int, default=0, help="override raw reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unsorted", action="store_true", help="leave the unique reads in random order")
+    ap.add_argument("--no-block-check", action="store_true", help="skip the MaxMatches per-block overflow check")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,7 +170,7 @@ def main() -> int:
     gathered_n = [0]
 
     def step():
-        n = eng.match_device(cfg, apply_mmtol=True)
+        n = eng.match_device(cfg, apply_mmtol=True, skip_block_check=args.no_block_check)
         if world > 1:
             h = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
             if n:
@@ -251,7 +252,7 @@ def main() -> int:
             },
             "per_step": {
                 "candidates": st["n_candidates"], "pairs": st["n_pairs"], "accepted": st["n_accepted"], "hits": st["n_hits"],
-                "hits_on_rank0": gathered_n[0], "read_windows": st["n_read_windows"],
+                "hits_on_rank0": gathered_n[0], "maxmatches_overflow_blocks": st["n_overflow_blocks"], "read_windows": st["n_read_windows"],
                 "ms_seed": acc["ms_seed"] / args.steps, "ms_scan": acc["ms_scan"] / args.steps,
                 "ms_expand": acc["ms_expand"] / args.steps, "ms_confirm": acc["ms_confirm"] / args.steps,
                 "ms_select": acc["ms_select"] / args.steps, "ms_device_total": acc["ms_total"] / args.steps,

@@ -70,7 +70,9 @@ typedef struct {
   /* Addition (the reference has no such flag; BASELINE.json's --MaxMismatch): 0 = budget from
    * PMatch as above; v > 0 = every read may have at most v-1 mismatches. */
   int32_t max_mismatch_p1;
-  int32_t reserved[4];
+  /* 1 = skip the per-block MaxMatches check (musc_stats.n_overflow_blocks becomes ~0) */
+  int32_t skip_block_check;
+  int32_t reserved[3];
 } musc_params;
 
 /* Counters and device timings of the last musc_match* call on a context. */
@@ -81,7 +83,10 @@ typedef struct {
   uint64_t n_pairs;         /* candidate pairs that reached the confirm kernel          */
   uint64_t n_accepted;      /* pairs with nmiss <= budget, after the union over windows */
   uint64_t n_hits;          /* tuples returned                                          */
-  uint64_t n_overflow_blocks; /* (window,key) blocks that may exceed MaxMatches (0 = exact) */
+  /* (window,key) blocks whose accepted pairs may exceed MaxMatches: 0 = proven none (the
+   * reference's truncation, cmd/muscato_confirm/main.go:233-242, 424-448, never triggered and
+   * the tuples are exact); > 0 = upper bound; ~0 = check skipped */
+  uint64_t n_overflow_blocks;
   uint64_t confirm_bytes;   /* algorithmic bytes of the confirm launches (63 B/pair at 100 bp) */
   uint32_t confirm_launches;
   uint32_t n_batches;

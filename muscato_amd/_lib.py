@@ -28,7 +28,8 @@ class MuscParams(ctypes.Structure):
         ("mmtol", ctypes.c_int32),
         ("apply_mmtol", ctypes.c_int32),
         ("max_mismatch_p1", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("skip_block_check", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 3),
     ]
 
 

@@ -90,7 +90,7 @@ class Config:
             c.ResultsFileName = "results.txt"
         return c
 
-    def to_params(self, apply_mmtol: bool) -> _lib.MuscParams:
+    def to_params(self, apply_mmtol: bool, skip_block_check: bool = False) -> _lib.MuscParams:
         c = self.with_defaults()
         if len(c.Windows) > _lib.MUSC_MAX_WINDOWS:
             raise MuscatoError("at most %d windows are supported" % _lib.MUSC_MAX_WINDOWS)
@@ -107,6 +107,7 @@ class Config:
         p.mmtol = int(c.MMTol)
         p.apply_mmtol = 1 if apply_mmtol else 0
         p.max_mismatch_p1 = c.MaxMismatch + 1 if c.MaxMismatch >= 0 else 0
+        p.skip_block_check = 1 if skip_block_check else 0
         return p
 
 
@@ -222,9 +223,9 @@ class Engine:
         self.n_reads = len(off) - 1
 
     # ---- hot path
-    def match_device(self, cfg: Config, apply_mmtol: bool = True) -> int:
+    def match_device(self, cfg: Config, apply_mmtol: bool = True, skip_block_check: bool = False) -> int:
         """Run screen+confirm(+select); hits stay on the device.  Returns the hit count."""
-        p = cfg.to_params(apply_mmtol)
+        p = cfg.to_params(apply_mmtol, skip_block_check)
         n = ctypes.c_uint64()
         self._check(self._lib.musc_match_device(self._h, ctypes.byref(p), ctypes.byref(n)), "musc_match_device")
         return int(n.value)

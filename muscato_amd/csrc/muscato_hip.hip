@@ -471,7 +471,11 @@ __global__ __launch_bounds__(256) void k_seed(const uint32_t* __restrict__ rd,
   block_add_u64(t64, &counters[3]);
 }
 
-#define NX_REJECT 0xFFFFu
+// per-pair result word: bits 0-15 mismatch count, bit 16 NX_DUP, bits 20-23 window
+#define NX_REJECT 0xFFFFFFFFu
+#define NX_DUP 0x10000u  // accepted through this window, but an earlier window reports the tuple
+#define NX_MASK 0x1FFFFu
+#define BLOCK_TABLE_BITS 22
 
 // Pair descriptor (16 B): x = read index within the batch, y = global base offset of the
 // placement, z = window k | z-flag << 4 | read's valid-window mask << 16, w = gene.
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256) void k_confirm(
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
     const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, int rw_rt,
     PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
-    uint16_t* __restrict__ p_nx, const uint32_t* __restrict__ npairs_dev) {
+    uint32_t* __restrict__ p_nx, const uint32_t* __restrict__ npairs_dev) {
   const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= *npairs_dev) return;
   const uint4 ds = cdesc[idx];
@@ -653,38 +657,81 @@ __global__ __launch_bounds__(256) void k_confirm(
         if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
     }
   }
-  const uint32_t kmin = exact ? (uint32_t)(__ffs(exact) - 1) : 0xFFu;
-  const bool ok = (kmin == k) && (nx <= nmiss_tab[len]);
-  __builtin_nontemporal_store(ok ? (uint16_t)nx : (uint16_t)NX_REJECT, &p_nx[idx]);
+  // own: the reference's confirm for window k accepts this pair (it counts towards that
+  // window-key block's MaxMatches); it is reported here only if k is the first such window.
+  const bool own = ((exact >> k) & 1u) && (nx <= nmiss_tab[len]);
+  const uint32_t kmin = (uint32_t)(__ffs(exact) - 1);
+  const uint32_t code = !own ? NX_REJECT : ((kmin == k ? nx : (nx | NX_DUP)) | (k << 20));
+  __builtin_nontemporal_store(code, &p_nx[idx]);
 }
 
 // Per-read selection, two passes around a scan (no per-hit atomics, deterministic order).
 // Pass 1, one thread per read: best mismatch count over its accepted pairs and the number of
 // tuples with nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60), or all
 // accepted tuples when apply_mmtol == 0.
+#define BLOCK_LDS_BITS 13
+
+// block_mode 0: no MaxMatches accounting.
+// block_mode 1: screening -- each workgroup keeps a count-min sketch of (window, key) -> pairs
+//   accepted through that window in LDS; if no sketch cell of any workgroup of any launch
+//   reaches `block_thr` = floor(MaxMatches / number of workgroup-launches), then by pigeonhole no
+//   block can hold more than MaxMatches pairs (cells only over-estimate).  Otherwise
+//   counters[6] is raised and the host repeats the pass in mode 2.
+// block_mode 2: exact -- one global atomic per (read, window) into a 2^22-cell table
+//   (70 M memory-side atomics per cfg3 pass, ~1.9 ms: only when mode 1 is inconclusive).
 __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
                                                     const uint32_t* __restrict__ cbase,
-                                                    const uint16_t* __restrict__ p_nx,
+                                                    const uint32_t* __restrict__ p_nx,
+                                                    const uint2* __restrict__ wsc, int block_mode,
+                                                    uint32_t block_thr,
+                                                    uint32_t* __restrict__ block_table,
                                                     uint32_t* __restrict__ hcnt,
                                                     uint32_t* __restrict__ hthr,
                                                     unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t s_sketch[1 << BLOCK_LDS_BITS];
+  if (block_mode == 1) {
+    for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += blockDim.x) s_sketch[t] = 0;
+    __syncthreads();
+  }
   unsigned long long acc = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t b = cbase[i], e = cbase[i + 1];
-    uint32_t best = NX_REJECT, na = 0;
+    uint32_t best = 0xFFFFFFFFu, na = 0;
+    // a read's pairs are stored window-major: count the pairs each window's confirm accepts
+    // and add them to that (window, key) block (cmd/muscato_confirm/main.go:233-242, 424-448
+    // truncate a block at MaxMatches).  The bucket start identifies the key.
+    uint32_t run_k = 0xFFFFFFFFu, run_n = 0;
+    auto flush_run = [&]() {
+      const uint64_t h = mix64(((uint64_t)run_k << 32) | wsc[(uint64_t)i * pp.W + run_k].x);
+      if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - BLOCK_LDS_BITS)], run_n);
+      else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], run_n);
+    };
     for (uint32_t j = b; j < e; j++) {
-      const uint32_t v = p_nx[j];
+      const uint32_t w = p_nx[j];
+      if (w == NX_REJECT) continue;
+      const uint32_t v = w & NX_MASK;
+      if (block_mode) {
+        const uint32_t k = w >> 20;
+        if (k != run_k) {
+          if (run_n) flush_run();
+          run_k = k;
+          run_n = 0;
+        }
+        run_n++;
+      }
+      if (v & NX_DUP) continue;
       best = v < best ? v : best;
-      na += v != NX_REJECT;
+      na++;
     }
+    if (block_mode && run_n) flush_run();
     uint32_t cnt = 0, thr = 0;
-    if (best != NX_REJECT) {
-      thr = pp.apply_mmtol ? best + (uint32_t)pp.mmtol : NX_REJECT - 1;
-      if (thr > NX_REJECT - 1) thr = NX_REJECT - 1;
+    if (best != 0xFFFFFFFFu) {
+      thr = pp.apply_mmtol ? best + (uint32_t)pp.mmtol : 0xFFFFu;
+      if (thr > 0xFFFFu) thr = 0xFFFFu;
       if (!pp.apply_mmtol) {
         cnt = na;
       } else {
-        for (uint32_t j = b; j < e; j++) cnt += p_nx[j] <= thr;
+        for (uint32_t j = b; j < e; j++) cnt += (p_nx[j] & NX_MASK) <= thr;  // REJECT/DUP are > thr
       }
     }
     hcnt[i] = cnt;
@@ -693,6 +740,22 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
   }
   block_add_u64(acc, &counters[1]);
   if (blockIdx.x == 0 && threadIdx.x == 0) hcnt[n] = 0;
+  if (block_mode == 1) {
+    __syncthreads();
+    uint32_t hot = 0;
+    for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += blockDim.x) hot |= s_sketch[t] >= block_thr;
+    if (__any(hot) && (threadIdx.x & 63) == 0) atomicOr(&counters[6], 1ull);
+  }
+}
+
+// number of block counters above MaxMatches (hash collisions only inflate counters, so 0 is
+// a proof that no window-key block overflowed)
+__global__ void k_block_overflow(const uint32_t* __restrict__ block_table, uint32_t max_matches,
+                                 unsigned long long* __restrict__ counters) {
+  unsigned long long c = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << BLOCK_TABLE_BITS); i += gridDim.x * blockDim.x)
+    c += block_table[i] > max_matches;
+  block_add_u64(c, &counters[5]);
 }
 
 // Pass 2, one thread per read: write its tuples at hits[counters[2] + hbase[i] ...].
@@ -700,7 +763,7 @@ __global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uin
                                               const uint32_t* __restrict__ hbase,
                                               const uint32_t* __restrict__ hthr,
                                               const uint4* __restrict__ cdesc,
-                                              const uint16_t* __restrict__ p_nx,
+                                              const uint32_t* __restrict__ p_nx,
                                               const uint64_t* __restrict__ seq_off,
                                               musc_hit* __restrict__ hits,
                                               const unsigned long long* __restrict__ counters) {
@@ -711,8 +774,8 @@ __global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uin
     unsigned long long slot = base + hbase[i];
     const uint32_t b = cbase[i], e = cbase[i + 1];
     for (uint32_t j = b; j < e; j++) {
-      const uint32_t v = p_nx[j];
-      if (v > thr) continue;  // NX_REJECT > thr always
+      const uint32_t v = p_nx[j] & NX_MASK;
+      if (v > thr) continue;  // NX_REJECT and NX_DUP codes are > thr always
       const uint4 ds = cdesc[j];
       musc_hit h;
       h.read_idx = (uint32_t)(r0 + i);
@@ -785,8 +848,10 @@ struct musc_ctx {
   DevBuf<uint2> wsc;
   DevBuf<uint32_t> rtot, rbase, vcnt, cbase, scan_tmp, hcnt, hbase, hthr;
   DevBuf<uint4> sdesc, cdesc;
-  DevBuf<uint16_t> p_nx;
+  DevBuf<uint32_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
+  DevBuf<uint32_t> block_table;
+  bool force_exact_blocks = false;
   unsigned long long* counters = nullptr;  // [0] valid windows [1] accepted [2] hit cursor
   uint64_t* h_pinned = nullptr;            // 4 x u64 pinned staging
 
@@ -1024,6 +1089,7 @@ void musc_destroy(musc_ctx* c) {
   c->scan_tmp.release(); c->hcnt.release(); c->hbase.release(); c->hthr.release();
   c->sdesc.release(); c->cdesc.release(); c->p_nx.release();
   c->nmiss_tab.release();
+  c->block_table.release();
   c->hits.release();
   if (c->counters) (void)hipFree(c->counters);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -1337,6 +1403,16 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   }
 
   HIPCHK(c, hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
+  // MaxMatches accounting (see k_best_count): screening first, exact only if inconclusive
+  const uint64_t planned_batches = (c->nreads + c->batch_reads - 1) / c->batch_reads + 1;
+  const uint64_t max_matches = P->max_matches > 0 ? (uint64_t)P->max_matches : 0x7FFFFFFFull;
+  const uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * MAX_GRID), 0x7FFFFFFFull);
+  int block_mode = P->skip_block_check ? 0 : (c->force_exact_blocks || block_thr < 2 ? 2 : 1);
+  const bool check_blocks = block_mode != 0;
+  if (block_mode == 2) {
+    if ((rc = ensure(c, c->block_table, 1ull << BLOCK_TABLE_BITS))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
+  }
   Timer tm(c);
   hipEvent_t ev0, ev1;
   HIPCHK(c, hipEventCreate(&ev0));
@@ -1423,8 +1499,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       c->stats.confirm_launches++;
 
       tm.begin(4);
-      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->cbase.p, c->p_nx.p, c->hcnt.p,
-                         c->hthr.p, c->counters);
+      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->cbase.p, c->p_nx.p,
+                         c->wsc.p, block_mode, block_thr, c->block_table.p, c->hcnt.p, c->hthr.p, c->counters);
       HIPCHK(c, hipGetLastError());
       rc = scan_u32(c, c->hcnt.p, c->hbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
       if (rc) return rc;
@@ -1437,14 +1513,32 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     }
     r0 += n;
   }
+  if (block_mode == 2) {
+    hipLaunchKernelGGL(k_block_overflow, dim3(1024), dim3(256), 0, c->stream, c->block_table.p,
+                       (uint32_t)(P->max_matches > 0 ? P->max_matches : 0x7FFFFFFF), c->counters);
+    HIPCHK(c, hipGetLastError());
+  }
   HIPCHK(c, hipEventRecord(ev1, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 7 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stats.n_read_windows = c->h_pinned[0];
   c->stats.n_accepted = c->h_pinned[1];
   c->stats.n_hits = c->nhits = c->h_pinned[2];
   c->stats.n_pairs = c->h_pinned[4];
   c->stats.n_candidates = n_slots;
+  // 0 = proven: no (window,key) block exceeded MaxMatches, the tuples equal the reference's;
+  // otherwise an upper bound on the number of such blocks (or ~0ull when the check was skipped)
+  c->stats.n_overflow_blocks = check_blocks ? c->h_pinned[5] : ~0ull;
+  if (block_mode == 1 && (c->h_pinned[6] || c->stats.n_batches > planned_batches)) {
+    // screening inconclusive (a hot sketch cell, or more launches than the threshold assumed):
+    // repeat the pass with exact per-block counters
+    c->force_exact_blocks = true;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    rc = musc_match_device(c, P, nhits);
+    c->force_exact_blocks = false;
+    return rc;
+  }
   c->stats.ms_seed = tm.total(0);
   c->stats.ms_scan = tm.total(1);
   c->stats.ms_expand = tm.total(2);

@@ -215,3 +215,45 @@ def test_stats_and_repeat_calls_are_stable(eng):
     assert_same(a, b)
     st = eng.stats()
     assert st["n_hits"] == len(a) and st["ms_total"] >= 0
+
+
+def test_maxmatches_overflow_is_detected(eng):
+    """cmd/muscato_confirm/main.go:233-242, 424-448: a (window,key) block with more than
+    MaxMatches accepted pairs is truncated order-dependently by the reference.  The GPU path keeps
+    every tuple and must say so: n_overflow_blocks > 0 exactly when a block overflows."""
+    key = b"ACGT"
+    targets = [key + bytes([b"ACGT"[(i >> s) & 3] for s in (0, 2)]) + b"AAAA" for i in range(12)]
+    reads = [key + b"AA"]
+    c = orc.Config(Windows=[0], WindowWidth=4, PMatch=0.5, MaxReadLength=50, MaxMatches=5)
+    got = gpu_hits(eng, c, reads, targets, False)
+    assert_same(got, as_arr(orc.match_direct(reads, targets, c, check_overflow=False)))
+    assert eng.stats()["n_overflow_blocks"] >= 1
+    lit = literal.match_literal(reads, targets, c)
+    assert set(map(tuple, lit)) < set(map(tuple, got.tolist()))   # the reference keeps a strict subset
+    c.MaxMatches = 12                                              # exactly at the limit: no truncation
+    got = gpu_hits(eng, c, reads, targets, False)
+    assert eng.stats()["n_overflow_blocks"] == 0
+    assert_same(got, np.array(literal.match_literal(reads, targets, c), dtype=np.uint32).reshape(-1, 4))
+    # two windows over the same placements: each window's block counts its own acceptances
+    c = orc.Config(Windows=[0, 1], WindowWidth=4, PMatch=0.5, MaxReadLength=50, MaxMatches=11)
+    gpu_hits(eng, c, reads, targets, False)
+    assert eng.stats()["n_overflow_blocks"] >= 1
+
+
+def test_no_overflow_reported_on_ordinary_cases(eng):
+    for seed in range(0, 40, 3):
+        ocfg, reads, targets = make_case(seed)
+        gpu_hits(eng, ocfg, reads, targets, True)
+        assert eng.stats()["n_overflow_blocks"] == 0
+
+
+def test_block_screening_falls_back_to_exact_counters(eng):
+    """MaxMatches = 20000 gives a screening threshold of 2 accepted pairs per workgroup sketch
+    cell: any multi-mapping read trips it and the pass is repeated with exact per-block counters;
+    the tuples and the verdict (no overflow) must not change."""
+    for seed in (2, 6, 11, 17):
+        ocfg, reads, targets = make_case(seed)
+        ocfg.MaxMatches = 20000
+        full = orc.match_direct(reads, targets, ocfg)
+        assert_same(gpu_hits(eng, ocfg, reads, targets, False), as_arr(full))
+        assert eng.stats()["n_overflow_blocks"] == 0
