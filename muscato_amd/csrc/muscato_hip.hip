@@ -477,11 +477,16 @@ __global__ __launch_bounds__(256) void k_seed(const uint32_t* __restrict__ rd,
 #define NX_MASK 0x1FFFFu
 #define BLOCK_TABLE_BITS 22
 
-// Pair descriptor (16 B): x = read index within the batch, y = global base offset of the
-// placement, z = window k | z-flag << 4 | read's valid-window mask << 16, w = gene.
+#define TILE 256  // reads per tile = threads per workgroup of the per-read kernels
+#define EXP_STAGE 4
 
-// k_expand -- one thread per read: walk its buckets and stage one descriptor per surviving
-// index entry at sdesc[rbase[i] ...]; vcnt[i] = number staged.
+// k_expand -- one workgroup per tile of 256 reads, one thread per read.  Each thread walks
+// its buckets, parks the descriptors of its first 4 surviving index entries in LDS and, after
+// a workgroup scan of the survivor counts, copies them densely from the tile's first slot
+// (desc[rbase[tile*256] ...]); a read with more survivors walks its buckets a second time
+// (entries the same CU has just fetched).  A tile's survivors are contiguous, a read's adjacent:
+// k_confirm takes one workgroup per tile and the per-read kernels use (cbase[i], vcnt[i]).
+//
 // The fit rules of cmd/muscato_screen/main.go:294-316 (target position 0, literal 100) and
 // :335-363 + cmd/muscato_confirm/main.go:201-203 (read must end inside the target) are
 // applied here from the distances stored in the entry.  A candidate whose 8+8 flanking bases
@@ -489,77 +494,154 @@ __global__ __launch_bounds__(256) void k_seed(const uint32_t* __restrict__ rd,
 // never be accepted by cdiff (cmd/muscato_confirm/main.go:205-211) and is dropped here, before
 // it costs a target gather (chance k-mer hits are about half of all candidates).  The flank
 // test never over-counts: an X is stored as code 0 on both sides.
+//
+// Descriptor (16 B): x = read index within the batch, y = global base offset of the
+// placement, z = window | z-flag << 4 | pos_ok << 5 | position in the target << 6 (when it
+// fits 16 bits exactly), w = gene.
 template <int RW>
-__global__ __launch_bounds__(256) void k_expand(const uint32_t* __restrict__ rd, uint64_t r0,
-                                                uint32_t n, int rw_rt, PathParams pp,
-                                                const uint16_t* __restrict__ nmiss_tab,
-                                                const uint2* __restrict__ wsc,
-                                                const uint32_t* __restrict__ rbase,
-                                                const uint4* __restrict__ entries,
-                                                uint4* __restrict__ sdesc, uint32_t* __restrict__ vcnt,
-                                                unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(TILE) void k_expand(const uint32_t* __restrict__ rd, uint64_t r0,
+                                                 uint32_t n, int rw_rt, PathParams pp,
+                                                 const uint16_t* __restrict__ nmiss_tab,
+                                                 const uint2* __restrict__ wsc,
+                                                 const uint32_t* __restrict__ rbase,
+                                                 const uint4* __restrict__ entries,
+                                                 uint4* __restrict__ desc, uint32_t* __restrict__ cbase,
+                                                 uint32_t* __restrict__ vcnt, uint32_t* __restrict__ rvalid,
+                                                 uint32_t* __restrict__ tcount,
+                                                 unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t s_wsum[TILE / 64];
+  __shared__ uint4 s_stage[TILE * EXP_STAGE];  // first EXP_STAGE survivors of each thread
   const int rw = RW ? RW : rw_rt;
+  const uint32_t ntiles = (n + TILE - 1) / TILE;
   unsigned long long nvalid = 0, npair = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t i = tile * TILE + threadIdx.x;
+    const bool active = i < n;
     Rec<RW> rec;
-    rec.load(rd + (r0 + i) * (uint64_t)rw, rw);
+    rec.load(rd + (r0 + (active ? i : 0)) * (uint64_t)rw, rw);
     const int len = (int)rec.len();
     const uint32_t budget = nmiss_tab[len];
-    uint64_t out = rbase[i];
-    const uint64_t out0 = out;
     uint32_t valid = 0;
-    for (int k = 0; k < pp.W; k++) valid |= (wsc[(uint64_t)i * pp.W + k].y >> 31) << k;
+    if (active)
+      for (int k = 0; k < pp.W; k++) valid |= (wsc[(uint64_t)i * pp.W + k].y >> 31) << k;
     nvalid += __popc(valid);
-    for (int k = 0; k < pp.W; k++) {
-      const uint2 sc = wsc[(uint64_t)i * pp.W + k];
-      const uint32_t c = sc.y & ~WSC_VALID;
-      if (c == 0) continue;
-      const int q1 = pp.win[k], q2 = q1 + pp.ww;
-      // the read's own flanks and which of their bases exist
-      const int nl = q1 < 8 ? q1 : 8;                                   // bases left of the window
-      const int nr = len - q2 < 8 ? (len - q2 < 0 ? 0 : len - q2) : 8;  // bases right of it
-      const uint32_t rfl = rec_flank_left(rec, (uint32_t)q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
-      const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
-                             ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
-      for (uint32_t e = 0; e < c; e++) {
-        const uint4 ent = entries[(uint64_t)sc.x + e];
-        const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
-        int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
-        const int tcap = left + right;  // target length, saturated (exact below 65535)
-        if (lim0 > tcap) lim0 = tcap;
-        const bool fit0 = len <= lim0;
-        bool ok = q1 <= left;                 // p = jx - q1 >= 0
-        if (left == 0) ok = ok && fit0;       // window at target position 0: pos-0 path
-        else ok = ok && (len - q1 <= right);  // p + len <= T
-        const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
-        const uint32_t x = rfl ^ ent.w;
-        const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
-        ok = ok && ((uint32_t)__popc(d) <= budget);
-        if (ok) {
-          sdesc[out] = make_uint4(i, ent.y - (uint32_t)q1, (uint32_t)k | (z << 4) | (valid << 16), ent.x);
-          out++;
+
+    // survivors: bit `ord` of surv for the ord-th entry of the read (first 64), count in cnt
+    auto walk = [&](bool write, uint64_t surv, uint64_t out) -> uint64_t {
+      uint32_t ord = 0, cnt = 0;
+      uint64_t bits = 0;
+      for (int k = 0; k < pp.W; k++) {
+        const uint2 sc = wsc[(uint64_t)i * pp.W + k];
+        const uint32_t c = sc.y & ~WSC_VALID;
+        if (c == 0) continue;
+        const int q1 = pp.win[k], q2 = q1 + pp.ww;
+        const int nl = q1 < 8 ? q1 : 8;                                   // bases left of the window
+        const int nr = len - q2 < 8 ? (len - q2 < 0 ? 0 : len - q2) : 8;  // bases right of it
+        const uint32_t rfl = rec_flank_left(rec, (uint32_t)q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+        const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
+                               ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
+        for (uint32_t e = 0; e < c; e++, ord++) {
+          if (write && ord < 64 && !((surv >> ord) & 1ull)) continue;
+          const uint4 ent = entries[(uint64_t)sc.x + e];
+          const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
+          int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
+          const int tcap = left + right;  // target length, saturated (exact below 65535)
+          if (lim0 > tcap) lim0 = tcap;
+          const bool fit0 = len <= lim0;
+          bool ok = q1 <= left;                 // p = jx - q1 >= 0
+          if (left == 0) ok = ok && fit0;       // window at target position 0: pos-0 path
+          else ok = ok && (len - q1 <= right);  // p + len <= T
+          const uint32_t x = rfl ^ ent.w;
+          const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
+          ok = ok && ((uint32_t)__popc(d) <= budget);
+          if (ok) {
+            const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
+            const uint32_t pos_ok = left < 65535 ? 1u : 0u;
+            const uint4 dd = make_uint4(i, ent.y - (uint32_t)q1,
+                                        (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
+            if (write) desc[out++] = dd;
+            else if (cnt < EXP_STAGE) s_stage[threadIdx.x * EXP_STAGE + cnt] = dd;
+          }
+          if (!write) {
+            if (ord < 64) bits |= (uint64_t)ok << ord;
+            cnt += ok;
+          }
         }
       }
+      (void)cnt;
+      return write ? out : bits;
+    };
+    // (in count mode the lambda returns the survivor bits of the first 64 entries)
+    uint64_t surv = 0;
+    uint32_t cnt = 0;
+    if (active) {
+      surv = walk(false, 0, 0);
+      cnt = (uint32_t)__popcll(surv);
+      uint32_t tot = 0;
+      for (int k = 0; k < pp.W; k++) tot += wsc[(uint64_t)i * pp.W + k].y & ~WSC_VALID;
+      if (tot > 64) {  // rare: count the survivors beyond the 64 tracked ones exactly
+        uint32_t ord = 0, extra = 0;
+        for (int k = 0; k < pp.W; k++) {
+          const uint2 sc = wsc[(uint64_t)i * pp.W + k];
+          const uint32_t c = sc.y & ~WSC_VALID;
+          const int q1 = pp.win[k], q2 = q1 + pp.ww;
+          const int nl = q1 < 8 ? q1 : 8;
+          const int nr = len - q2 < 8 ? (len - q2 < 0 ? 0 : len - q2) : 8;
+          const uint32_t rfl = rec_flank_left(rec, (uint32_t)q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+          const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
+                                 ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
+          for (uint32_t e = 0; e < c; e++, ord++) {
+            if (ord < 64) continue;
+            const uint4 ent = entries[(uint64_t)sc.x + e];
+            const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
+            int lim0 = 100 - pp.ww;
+            const int tcap = left + right;
+            if (lim0 > tcap) lim0 = tcap;
+            const bool fit0 = len <= lim0;
+            bool ok = q1 <= left;
+            if (left == 0) ok = ok && fit0; else ok = ok && (len - q1 <= right);
+            const uint32_t x = rfl ^ ent.w;
+            ok = ok && ((uint32_t)__popc((x | (x >> 1)) & 0x55555555u & fmask) <= budget);
+            extra += ok;
+          }
+        }
+        cnt += extra;
+      }
     }
-    vcnt[i] = (uint32_t)(out - out0);
-    npair += out - out0;
+    // workgroup exclusive scan of cnt
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();  // previous iteration's readers of s_wsum are done
+    if (lane == 63) s_wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < TILE / 64; w++) {
+      if (w < wid) woff += s_wsum[w];
+      total += s_wsum[w];
+    }
+    const uint32_t tbase = rbase[tile * TILE];
+    const uint32_t mine = tbase + woff + inc - cnt;
+    if (active) {
+      cbase[i] = mine;
+      vcnt[i] = cnt;
+      rvalid[i] = valid;
+      if (cnt <= EXP_STAGE) {
+        for (uint32_t q = 0; q < cnt; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
+      } else {
+        walk(true, surv, mine);
+      }
+      npair += cnt;
+    }
+    if (threadIdx.x == 0) tcount[tile] = total;
   }
   block_add_u64(nvalid, &counters[0]);
   block_add_u64(npair, &counters[4]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) vcnt[n] = 0;
-}
-
-// k_compact -- one thread per read: move its staged descriptors to their compact position,
-// so that k_confirm only sees surviving pairs and a read's pairs stay adjacent.
-__global__ __launch_bounds__(256) void k_compact(uint32_t n, const uint32_t* __restrict__ rbase,
-                                                 const uint32_t* __restrict__ cbase,
-                                                 const uint4* __restrict__ sdesc,
-                                                 uint4* __restrict__ cdesc) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t c0 = cbase[i], c1 = cbase[i + 1];
-    const uint64_t s0 = rbase[i];
-    for (uint32_t j = c0; j < c1; j++) cdesc[j] = sdesc[s0 + (j - c0)];
-  }
 }
 
 // u32 mask of the bits of window [q1, q1+ww) (2 bits per base) that fall in record word j
@@ -582,16 +664,21 @@ struct __attribute__((packed, aligned(4))) u32x4_u {
 // (cmd/muscato_confirm/main.go:151-159, 205-211; X==X through the mask plane), then decides
 // whether THIS window is the first window of the read that the reference would have emitted
 // the tuple through (exact window key + fit), which makes the union over windows a set
-// without a sort.  RW = record words (compile time) or 0 = runtime stride.  The pair count
-// comes from device memory (cbase[n]) so that no host round trip sits in front of the launch.
+// without a sort.  RW = record words (compile time) or 0 = runtime stride.  One workgroup per
+// tile of k_expand: its pairs are desc[rbase[tile*256] .. +tcount[tile]), counts stay on the
+// device so no host round trip sits in front of the launch.
 template <int RW, bool MASK>
 __global__ __launch_bounds__(256) void k_confirm(
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
     const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, int rw_rt,
     PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
-    uint32_t* __restrict__ p_nx, const uint32_t* __restrict__ npairs_dev) {
-  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= *npairs_dev) return;
+    const uint32_t* __restrict__ rvalid, uint32_t* __restrict__ p_nx,
+    const uint32_t* __restrict__ rbase, const uint32_t* __restrict__ tcount) {
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tn = tcount[tile];
+  const uint64_t tb = rbase[tile * TILE];
+  for (uint32_t tj = threadIdx.x; tj < tn; tj += blockDim.x) {
+  const uint64_t idx = tb + tj;
   const uint4 ds = cdesc[idx];
   const uint32_t ri = ds.x;
   const int rw = RW ? RW : rw_rt;
@@ -600,7 +687,7 @@ __global__ __launch_bounds__(256) void k_confirm(
   const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)rw;
   const uint64_t widx = gpos >> 4;
   const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
-  uint32_t exact = ds.z >> 16;
+  uint32_t exact = rvalid[ri];
   if (z) exact &= ~pp.q1zero_mask;
 
   uint32_t nx = 0, len;
@@ -663,13 +750,14 @@ __global__ __launch_bounds__(256) void k_confirm(
   const uint32_t kmin = (uint32_t)(__ffs(exact) - 1);
   const uint32_t code = !own ? NX_REJECT : ((kmin == k ? nx : (nx | NX_DUP)) | (k << 20));
   __builtin_nontemporal_store(code, &p_nx[idx]);
+  }
 }
 
 // Per-read selection, two passes around a scan (no per-hit atomics, deterministic order).
 // Pass 1, one thread per read: best mismatch count over its accepted pairs and the number of
 // tuples with nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60), or all
 // accepted tuples when apply_mmtol == 0.
-#define BLOCK_LDS_BITS 13
+#define BLOCK_LDS_BITS 11
 
 // block_mode 0: no MaxMatches accounting.
 // block_mode 1: screening -- each workgroup keeps a count-min sketch of (window, key) -> pairs
@@ -681,6 +769,7 @@ __global__ __launch_bounds__(256) void k_confirm(
 //   (70 M memory-side atomics per cfg3 pass, ~1.9 ms: only when mode 1 is inconclusive).
 __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
                                                     const uint32_t* __restrict__ cbase,
+                                                    const uint32_t* __restrict__ vcnt,
                                                     const uint32_t* __restrict__ p_nx,
                                                     const uint2* __restrict__ wsc, int block_mode,
                                                     uint32_t block_thr,
@@ -695,41 +784,58 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
   }
   unsigned long long acc = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t b = cbase[i], e = cbase[i + 1];
-    uint32_t best = 0xFFFFFFFFu, na = 0;
+    const uint32_t b = cbase[i], e = b + vcnt[i];
+    uint32_t best = 0xFFFFFFFFu, na = 0, nbest = 0;
     // a read's pairs are stored window-major: count the pairs each window's confirm accepts
     // and add them to that (window, key) block (cmd/muscato_confirm/main.go:233-242, 424-448
     // truncate a block at MaxMatches).  The bucket start identifies the key.
-    uint32_t run_k = 0xFFFFFFFFu, run_n = 0;
-    auto flush_run = [&]() {
-      const uint64_t h = mix64(((uint64_t)run_k << 32) | wsc[(uint64_t)i * pp.W + run_k].x);
-      if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - BLOCK_LDS_BITS)], run_n);
-      else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], run_n);
-    };
+    // per-window accepted counts, 8 bits each (windows 0-7 in wc0, 8-15 in wc1); a count
+    // that would pass 255 raises the "hot" flag instead (=> exact pass)
+    uint64_t wc0 = 0, wc1 = 0;
+    bool sat = false;
     for (uint32_t j = b; j < e; j++) {
       const uint32_t w = p_nx[j];
       if (w == NX_REJECT) continue;
       const uint32_t v = w & NX_MASK;
       if (block_mode) {
         const uint32_t k = w >> 20;
-        if (k != run_k) {
-          if (run_n) flush_run();
-          run_k = k;
-          run_n = 0;
-        }
-        run_n++;
+        uint64_t& wc = k < 8 ? wc0 : wc1;
+        const uint32_t sh = (k & 7u) * 8u;
+        if (((wc >> sh) & 0xFFull) == 0xFFull) sat = true; else wc += 1ull << sh;
       }
       if (v & NX_DUP) continue;
+      nbest = v < best ? 1u : (v == best ? nbest + 1u : nbest);
       best = v < best ? v : best;
       na++;
     }
-    if (block_mode && run_n) flush_run();
+    if (block_mode == 2 && sat) {
+      // a read with more than 255 accepted pairs in one window: count pair by pair (rare)
+      for (uint32_t j = b; j < e; j++) {
+        const uint32_t w = p_nx[j];
+        if (w == NX_REJECT) continue;
+        const uint32_t k = w >> 20;
+        const uint64_t h = mix64(((uint64_t)k << 32) | wsc[(uint64_t)i * pp.W + k].x);
+        atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], 1u);
+      }
+    } else if (block_mode) {
+      for (int k = 0; k < pp.W; k++) {  // uniform loop: the atomics of a wave issue together
+        const uint32_t cw = (uint32_t)(((k < 8 ? wc0 : wc1) >> ((k & 7) * 8)) & 0xFFull);
+        if (cw) {
+          const uint64_t h = mix64(((uint64_t)k << 32) | wsc[(uint64_t)i * pp.W + k].x);
+          if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - BLOCK_LDS_BITS)], cw);
+          else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
+        }
+      }
+      if (sat) atomicOr(&counters[6], 1ull);  // screening cannot bound this read: exact pass
+    }
     uint32_t cnt = 0, thr = 0;
     if (best != 0xFFFFFFFFu) {
       thr = pp.apply_mmtol ? best + (uint32_t)pp.mmtol : 0xFFFFu;
       if (thr > 0xFFFFu) thr = 0xFFFFu;
       if (!pp.apply_mmtol) {
         cnt = na;
+      } else if (pp.mmtol == 0) {
+        cnt = nbest;  // tuples at the best count, found in the same pass
       } else {
         for (uint32_t j = b; j < e; j++) cnt += (p_nx[j] & NX_MASK) <= thr;  // REJECT/DUP are > thr
       }
@@ -760,6 +866,7 @@ __global__ void k_block_overflow(const uint32_t* __restrict__ block_table, uint3
 
 // Pass 2, one thread per read: write its tuples at hits[counters[2] + hbase[i] ...].
 __global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uint32_t* __restrict__ cbase,
+                                              const uint32_t* __restrict__ vcnt,
                                               const uint32_t* __restrict__ hbase,
                                               const uint32_t* __restrict__ hthr,
                                               const uint4* __restrict__ cdesc,
@@ -772,7 +879,7 @@ __global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uin
     const uint32_t thr = hthr[i];
     if (thr == 0xFFFFFFFFu) continue;
     unsigned long long slot = base + hbase[i];
-    const uint32_t b = cbase[i], e = cbase[i + 1];
+    const uint32_t b = cbase[i], e = b + vcnt[i];
     for (uint32_t j = b; j < e; j++) {
       const uint32_t v = p_nx[j] & NX_MASK;
       if (v > thr) continue;  // NX_REJECT and NX_DUP codes are > thr always
@@ -780,7 +887,9 @@ __global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uin
       musc_hit h;
       h.read_idx = (uint32_t)(r0 + i);
       h.gene_idx = ds.w;
-      h.pos = (uint32_t)((uint64_t)ds.y - seq_off[ds.w]);
+      // position in the target: carried in the descriptor unless the target is so long that
+      // the entry's 16-bit distance saturated (then one gather of the gene's offset)
+      h.pos = ((ds.z >> 5) & 1u) ? (ds.z >> 6) : (uint32_t)((uint64_t)ds.y - seq_off[ds.w]);
       h.nmiss = v;
       *reinterpret_cast<uint4*>(&hits[slot++]) = make_uint4(h.read_idx, h.gene_idx, h.pos, h.nmiss);
     }
@@ -846,8 +955,8 @@ struct musc_ctx {
 
   // per-batch work buffers
   DevBuf<uint2> wsc;
-  DevBuf<uint32_t> rtot, rbase, vcnt, cbase, scan_tmp, hcnt, hbase, hthr;
-  DevBuf<uint4> sdesc, cdesc;
+  DevBuf<uint32_t> rtot, rbase, vcnt, cbase, rvalid, tcount, scan_tmp, hcnt, hbase, hthr;
+  DevBuf<uint4> cdesc;
   DevBuf<uint32_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
   DevBuf<uint32_t> block_table;
@@ -1017,15 +1126,17 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
                        c->wsc.p, c->rtot.p, c->counters);
   } else if (stage == 1) {
     hipLaunchKernelGGL((k_expand<RW>), rgrid, block, 0, c->stream, c->rd, r0, n, c->rw, pp, c->nmiss_tab.p,
-                       c->wsc.p, c->rbase.p, c->idx_entries, c->sdesc.p, c->vcnt.p, c->counters);
+                       c->wsc.p, c->rbase.p, c->idx_entries, c->cdesc.p, c->cbase.p, c->vcnt.p, c->rvalid.p,
+                       c->tcount.p, c->counters);
   } else {
-    const dim3 grid(nblk(slots, 256));
+    const dim3 grid(nblk(n, TILE));  // one workgroup per k_expand tile
+    (void)slots;
     if (mask)
       hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->p_nx.p, c->cbase.p + n);
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->rbase.p, c->tcount.p);
     else
       hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->p_nx.p, c->cbase.p + n);
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->rbase.p, c->tcount.p);
   }
 }
 
@@ -1087,7 +1198,7 @@ void musc_destroy(musc_ctx* c) {
   free_reads(c);
   c->wsc.release(); c->rtot.release(); c->rbase.release(); c->vcnt.release(); c->cbase.release();
   c->scan_tmp.release(); c->hcnt.release(); c->hbase.release(); c->hthr.release();
-  c->sdesc.release(); c->cdesc.release(); c->p_nx.release();
+  c->rvalid.release(); c->tcount.release(); c->cdesc.release(); c->p_nx.release();
   c->nmiss_tab.release();
   c->block_table.release();
   c->hits.release();
@@ -1444,6 +1555,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if ((rc = ensure(c, c->rbase, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->vcnt, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->cbase, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->rvalid, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->tcount, (uint64_t)nblk(n, TILE) + 1))) return rc;
     if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)n + 1)))) return rc;
     if ((rc = ensure(c, c->hcnt, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->hbase, (uint64_t)n + 1))) return rc;
@@ -1472,7 +1585,6 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     }
     c->stats.n_batches++;
     n_slots += total;
-    if ((rc = ensure(c, c->sdesc, total))) return rc;
     if ((rc = ensure(c, c->cdesc, total))) return rc;
     if ((rc = ensure(c, c->p_nx, total))) return rc;
     if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
@@ -1481,16 +1593,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     launch_stage(c, 1, mask, r0, n, pp, 0);
     HIPCHK(c, hipGetLastError());
     tm.end(2);
-    tm.begin(1);
-    rc = scan_u32(c, c->vcnt.p, c->cbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
-    if (rc) return rc;
-    tm.end(1);
     if (total) {
       const dim3 sg(std::min(nblk(n, 256), MAX_GRID));
-      tm.begin(2);
-      hipLaunchKernelGGL(k_compact, sg, dim3(256), 0, c->stream, n, c->rbase.p, c->cbase.p, c->sdesc.p, c->cdesc.p);
-      HIPCHK(c, hipGetLastError());
-      tm.end(2);
 
       tm.begin(3);
       launch_stage(c, 2, mask, r0, n, pp, total);
@@ -1499,12 +1603,12 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       c->stats.confirm_launches++;
 
       tm.begin(4);
-      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->cbase.p, c->p_nx.p,
+      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->cbase.p, c->vcnt.p, c->p_nx.p,
                          c->wsc.p, block_mode, block_thr, c->block_table.p, c->hcnt.p, c->hthr.p, c->counters);
       HIPCHK(c, hipGetLastError());
       rc = scan_u32(c, c->hcnt.p, c->hbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_emit, sg, dim3(256), 0, c->stream, r0, n, c->cbase.p, c->hbase.p, c->hthr.p, c->cdesc.p,
+      hipLaunchKernelGGL(k_emit, sg, dim3(256), 0, c->stream, r0, n, c->cbase.p, c->vcnt.p, c->hbase.p, c->hthr.p, c->cdesc.p,
                          c->p_nx.p, c->seq_off, c->hits.p, c->counters);
       HIPCHK(c, hipGetLastError());
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->hbase.p, n, c->counters);
