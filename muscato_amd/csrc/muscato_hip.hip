@@ -209,6 +209,30 @@ __global__ void k_pack_reads(const unsigned char* __restrict__ s, const uint32_t
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
 
+// 8 consecutive elements per thread, moved as two 16-byte accesses when the whole group is
+// in range (all pointers handed to the scan are 16-byte aligned)
+DEV void scan_load8(const uint32_t* __restrict__ in, uint64_t base, uint64_t n, uint32_t (&v)[SCAN_ITEMS]) {
+  if (base + SCAN_ITEMS <= n) {
+    const uint4 a = *reinterpret_cast<const uint4*>(in + base);
+    const uint4 b = *reinterpret_cast<const uint4*>(in + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) v[i] = (base + i < n) ? in[base + i] : 0u;
+  }
+}
+
+DEV void scan_store8(uint32_t* __restrict__ out, uint64_t base, uint64_t n, const uint32_t (&v)[SCAN_ITEMS]) {
+  if (base + SCAN_ITEMS <= n) {
+    *reinterpret_cast<uint4*>(out + base) = make_uint4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<uint4*>(out + base + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+      if (base + i < n) out[base + i] = v[i];
+  }
+}
+
 template <bool INCLUSIVE>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t* __restrict__ in,
                                                           uint32_t* __restrict__ out,
@@ -217,12 +241,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t* __res
   __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
+  scan_load8(in, base, n, v);
   uint32_t sum = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    v[i] = (base + i < n) ? in[base + i] : 0u;
-    sum += v[i];
-  }
+  for (int i = 0; i < SCAN_ITEMS; i++) sum += v[i];
   // wave inclusive scan of the per-thread sums
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   uint32_t inc = sum;
@@ -242,10 +264,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t* __res
   uint32_t run = wave_off + inc - sum;  // exclusive prefix of this thread
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
-    if (INCLUSIVE) run += v[i];
-    if (base + i < n) out[base + i] = run;
-    if (!INCLUSIVE) run += v[i];
+    const uint32_t x = v[i];
+    v[i] = INCLUSIVE ? run + x : run;
+    run += x;
   }
+  scan_store8(out, base, n, v);
   if (block_sums && threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
@@ -254,9 +277,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ 
                                                         uint64_t n) {
   const uint32_t add = block_off[blockIdx.x];
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  scan_load8(out, base, n, v);
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++)
-    if (base + i < n) out[base + i] += add;
+  for (int i = 0; i < SCAN_ITEMS; i++) v[i] += add;
+  scan_store8(out, base, n, v);
 }
 
 // ------------------------------------------------------------------------------------
@@ -653,6 +678,8 @@ DEV uint32_t window_word_mask(int q1, int ww, int j) {
   return mh & ml;
 }
 
+typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+
 // 16 bytes at a dword-aligned address (global memory allows it on gfx950)
 struct __attribute__((packed, aligned(4))) u32x4_u {
   uint32_t x, y, z, w;
@@ -679,7 +706,10 @@ __global__ __launch_bounds__(256) void k_confirm(
   const uint64_t tb = rbase[tile * TILE];
   for (uint32_t tj = threadIdx.x; tj < tn; tj += blockDim.x) {
   const uint64_t idx = tb + tj;
-  const uint4 ds = cdesc[idx];
+  // descriptors, read records and results stream through once: non-temporal, so that the
+  // database -- the only operand with reuse -- keeps the Infinity Cache
+  const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + idx);
+  const uint4 ds = make_uint4(dsv.x, dsv.y, dsv.z, dsv.w);
   const uint32_t ri = ds.x;
   const int rw = RW ? RW : rw_rt;
   const uint64_t gpos = ds.y;
@@ -696,7 +726,7 @@ __global__ __launch_bounds__(256) void k_confirm(
     uint32_t r[RW], t[RW], rm[RW], tm[RW];
 #pragma unroll
     for (int q = 0; q < RW / 4; q++) {
-      const uint4 a = *reinterpret_cast<const uint4*>(rec + 4 * q);
+      const u32x4_v a = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(rec) + q);
       r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
       const u32x4_u b = *reinterpret_cast<const u32x4_u*>(db2 + widx + 4 * q);
       t[4 * q] = b.x; t[4 * q + 1] = b.y; t[4 * q + 2] = b.z; t[4 * q + 3] = b.w;
@@ -1018,7 +1048,7 @@ uint64_t scan_tmp_elems(uint64_t n) {
   uint64_t t = 0;
   while (n > SCAN_TILE) {
     n = (n + SCAN_TILE - 1) / SCAN_TILE;
-    t += n + 8;
+    t += (n + 8 + 3) & ~3ull;
   }
   return t + 8;
 }
@@ -1036,7 +1066,7 @@ int scan_u32(musc_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, bool in
   if (inclusive) hipLaunchKernelGGL(k_scan_block<true>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, out, sums, n);
   else hipLaunchKernelGGL(k_scan_block<false>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, out, sums, n);
   HIPCHK(c, hipGetLastError());
-  int rc = scan_u32(c, sums, sums, nb, false, tmp + nb + 8);
+  int rc = scan_u32(c, sums, sums, nb, false, tmp + ((nb + 8 + 3) & ~3ull));
   if (rc) return rc;
   hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, out, sums, n);
   HIPCHK(c, hipGetLastError());
