@@ -285,20 +285,31 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
-// database index: bucket -> list of (gene, window start).  A has 2^bits + 2 counters:
-// counts land in A[b+2]; after an inclusive scan A[b+1] = start(b); the scatter pass
-// bumps A[b+1], leaving A[b] = start(b), A[b+1] = end(b).
-// ------------------------------------------------------------------------------------
-
-// One index entry (16 B, one dwordx4): everything k_expand needs about a window start
+// database index: a table of 64-byte buckets, one per k-mer key (direct) or key hash.
+//   Bucket = { count, cursor (build only), overflow start, 3 inline entries }.
+// A probe is ONE 64-byte access (half a 128-B line, the unit every L2 miss fetches on
+// gfx950): count and the first three entries arrive together; only buckets with more than
+// three entries (1.5 % of the chance buckets at 1 Gbp / 15-mers) touch the overflow list E.
+//
+// One index entry (16 B, one dwordx4): everything k_screen needs about a window start
 // without touching the per-gene offset table.
 //   x gene   : target number
 //   y gposw  : global base offset of the window start (low 32 bits)
 //   z lr     : min(jx, 65535) | min(T - jx, 65535) << 16  (distances to the gene's two ends,
 //              saturated: window starts and read lengths are < 65535, so every comparison
-//              k_expand makes against them is exact)
+//              k_screen makes against them is exact)
 //   w flank  : the 8 bases left of the window (bits 0-15, base jx-1 in bits 14-15) and the
 //              8 bases right of it (bits 16-31, base jx+ww in bits 16-17), 2 bits each
+// ------------------------------------------------------------------------------------
+#define BUCKET_INLINE 3
+struct __attribute__((aligned(64))) Bucket {
+  uint32_t count;
+  uint32_t cursor;
+  uint64_t ovf;
+  uint4 e[BUCKET_INLINE];
+};
+static_assert(sizeof(Bucket) == 64, "bucket must be half a cache line");
+
 DEV uint32_t flank_left(const uint32_t* __restrict__ w, uint64_t base) {
   // 8 bases ending just before base index `base` of plane w (zeros before the stream start)
   if (base >= 8) return (uint32_t)ext64(w, 2 * (base - 8)) & 0xFFFFu;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256) void k_index(const uint32_t* __restrict__ db2,
                                                const uint32_t* __restrict__ dbm2,
                                                const uint64_t* __restrict__ seq_off, uint32_t nseq,
                                                uint64_t nbases, int ww, int bits, int direct,
-                                               uint32_t* __restrict__ A, uint4* __restrict__ entries) {
+                                               Bucket* __restrict__ T, uint4* __restrict__ E) {
   __shared__ uint32_t s_g0;
   const uint64_t gfirst = (uint64_t)blockIdx.x * blockDim.x;
   if (threadIdx.x == 0) {
@@ -331,14 +342,32 @@ __global__ __launch_bounds__(256) void k_index(const uint32_t* __restrict__ db2,
   if (jx + (uint64_t)ww > e - s) return;  // window would cross the target end
   const uint32_t b = bucket_of(db2, dbm2, 2 * g, ww, bits, direct);
   if (!SCATTER) {
-    atomicAdd(&A[(uint64_t)b + 2], 1u);
+    atomicAdd(&T[b].count, 1u);
   } else {
-    const uint32_t slot = atomicAdd(&A[(uint64_t)b + 1], 1u);
+    const uint32_t slot = atomicAdd(&T[b].cursor, 1u);
     const uint64_t rem = e - g;  // T - jx
     const uint32_t lr = (uint32_t)(jx > 65535 ? 65535 : jx) | ((uint32_t)(rem > 65535 ? 65535 : rem) << 16);
     const uint32_t fl = flank_left(db2, g) | (((uint32_t)ext64(db2, 2 * (g + (uint64_t)ww)) & 0xFFFFu) << 16);
-    entries[slot] = make_uint4(gene, (uint32_t)g, lr, fl);
+    const uint4 ent = make_uint4(gene, (uint32_t)g, lr, fl);
+    if (slot < BUCKET_INLINE) T[b].e[slot] = ent;
+    else E[T[b].ovf + (slot - BUCKET_INLINE)] = ent;
   }
+}
+
+// overflow list sizes: tmp[b] = max(count - 3, 0), scanned on the side, written back as ovf
+__global__ void k_index_ovf_count(const Bucket* __restrict__ T, uint64_t nb, uint32_t* __restrict__ tmp) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) {
+    const uint32_t c = T[b].count;
+    tmp[b] = c > BUCKET_INLINE ? c - BUCKET_INLINE : 0u;
+  } else if (b == nb) {
+    tmp[b] = 0;
+  }
+}
+
+__global__ void k_index_ovf_set(Bucket* __restrict__ T, uint64_t nb, const uint32_t* __restrict__ tmp) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) T[b].ovf = tmp[b];
 }
 
 // ------------------------------------------------------------------------------------
@@ -449,190 +478,130 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
   return __popc(seen);
 }
 
-#define WSC_VALID 0x80000000u
-
-// k_seed -- one thread per read: which windows take part
-// (cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185) and the
-// index bucket [start, start+count) each one probes.  wsc[i*W+k] = (start, count | VALID).
-template <int RW>
-__global__ __launch_bounds__(256) void k_seed(const uint32_t* __restrict__ rd,
-                                              const uint32_t* __restrict__ rdm, uint64_t r0,
-                                              uint32_t n, int rw_rt, PathParams pp,
-                                              const uint32_t* __restrict__ A,
-                                              uint2* __restrict__ wsc, uint32_t* __restrict__ rtot,
-                                              unsigned long long* __restrict__ counters) {
-  const int rw = RW ? RW : rw_rt;
-  const bool has_m = rdm != nullptr;
-  unsigned long long t64 = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint64_t r = r0 + i;
-    Rec<RW> rec;
-    rec.load(rd + r * (uint64_t)rw, rw);
-    Rec<RW> recm = rec;  // placeholder, only read under has_m
-    if (has_m) recm.load(rdm + r * (uint64_t)rw, rw);
-    const uint32_t len = rec.len();
-    uint32_t tot = 0;
-    for (int k = 0; k < pp.W; k++) {
-      const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
-      uint32_t s = 0, c = 0;
-      if (len >= q2) {
-        const bool ok = pp.min_dinuc <= 0 || rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
-        if (ok) {
-          const uint32_t b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
-          // A[b], A[b+1]: one 8-byte load (dword aligned)
-          struct __attribute__((packed, aligned(4))) u32x2_u { uint32_t x, y; };
-          const u32x2_u se = *reinterpret_cast<const u32x2_u*>(A + b);
-          s = se.x;
-          c = (se.y - se.x) | WSC_VALID;
-        }
-      }
-      wsc[(uint64_t)i * pp.W + k] = make_uint2(s, c);
-      tot += c & ~WSC_VALID;
-    }
-    rtot[i] = tot;
-    t64 += tot;
-  }
-  // 64-bit total of candidate slots of this launch (the u32 scan could wrap)
-  block_add_u64(t64, &counters[3]);
-}
-
 // per-pair result word: bits 0-15 mismatch count, bit 16 NX_DUP, bits 20-23 window
 #define NX_REJECT 0xFFFFFFFFu
 #define NX_DUP 0x10000u  // accepted through this window, but an earlier window reports the tuple
 #define NX_MASK 0x1FFFFu
 #define BLOCK_TABLE_BITS 22
+#define WB_NONE 0xFFFFFFFFu
 
-#define TILE 256  // reads per tile = threads per workgroup of the per-read kernels
+#define TILE 256  // reads per tile = threads per workgroup of k_screen
 #define EXP_STAGE 4
 
-// k_expand -- one workgroup per tile of 256 reads, one thread per read.  Each thread walks
-// its buckets, parks the descriptors of its first 4 surviving index entries in LDS and, after
-// a workgroup scan of the survivor counts, copies them densely from the tile's first slot
-// (desc[rbase[tile*256] ...]); a read with more survivors walks its buckets a second time
-// (entries the same CU has just fetched).  A tile's survivors are contiguous, a read's adjacent:
-// k_confirm takes one workgroup per tile and the per-read kernels use (cbase[i], vcnt[i]).
+// k_screen -- muscato_screen + the join, fused: one workgroup per tile of 256 reads, one
+// thread per read.  For each window of the read that takes part
+// (cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185: long enough,
+// CountDinuc >= MinDinuc) the thread probes the window's index bucket and walks its entries
+// (three arrive with the probe).  From the entry alone it applies p = jx - q1 >= 0, the fit
+// rules of cmd/muscato_screen/main.go:294-316 (target position 0: the literal 100) and
+// :335-363 + cmd/muscato_confirm/main.go:201-203 (the read must end inside the target), and a
+// flank pre-filter: a candidate whose 8+8 flanking bases already disagree with the read in
+// more places than the read's whole mismatch budget can never be accepted by cdiff
+// (cmd/muscato_confirm/main.go:205-211) and is dropped before it costs a target gather (chance
+// k-mer hits are about half of all candidates).  The flank test never over-counts: an X is
+// stored as code 0 on both sides.
 //
-// The fit rules of cmd/muscato_screen/main.go:294-316 (target position 0, literal 100) and
-// :335-363 + cmd/muscato_confirm/main.go:201-203 (read must end inside the target) are
-// applied here from the distances stored in the entry.  A candidate whose 8+8 flanking bases
-// already disagree with the read in more places than the read's whole mismatch budget can
-// never be accepted by cdiff (cmd/muscato_confirm/main.go:205-211) and is dropped here, before
-// it costs a target gather (chance k-mer hits are about half of all candidates).  The flank
-// test never over-counts: an X is stored as code 0 on both sides.
+// Survivors: the first 4 descriptors of a thread wait in LDS; after a workgroup scan of the
+// counts the tile claims a contiguous range of `desc` with one atomic and the threads copy
+// their descriptors in read order (a read with more survivors walks its buckets again).  A
+// tile's pairs are contiguous and a read's pairs adjacent, window-major; tile ranges are in
+// arrival order, which nothing downstream depends on (k_emit orders the tuples by read).
 //
 // Descriptor (16 B): x = read index within the batch, y = global base offset of the
 // placement, z = window | z-flag << 4 | pos_ok << 5 | position in the target << 6 (when it
 // fits 16 bits exactly), w = gene.
+// counters: [0] valid windows, [3] candidates (index entries walked), [4] pairs,
+//           [7] desc cursor (also the number of pairs the batch needs).
 template <int RW>
-__global__ __launch_bounds__(TILE) void k_expand(const uint32_t* __restrict__ rd, uint64_t r0,
+__global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd,
+                                                 const uint32_t* __restrict__ rdm, uint64_t r0,
                                                  uint32_t n, int rw_rt, PathParams pp,
                                                  const uint16_t* __restrict__ nmiss_tab,
-                                                 const uint2* __restrict__ wsc,
-                                                 const uint32_t* __restrict__ rbase,
-                                                 const uint4* __restrict__ entries,
-                                                 uint4* __restrict__ desc, uint32_t* __restrict__ cbase,
-                                                 uint32_t* __restrict__ vcnt, uint32_t* __restrict__ rvalid,
+                                                 const Bucket* __restrict__ T,
+                                                 const uint4* __restrict__ E,
+                                                 uint4* __restrict__ desc, uint64_t desc_cap,
+                                                 uint32_t* __restrict__ cbase,
+                                                 uint32_t* __restrict__ vcnt,
+                                                 uint32_t* __restrict__ rvalid,
+                                                 uint32_t* __restrict__ wb,
+                                                 uint32_t* __restrict__ tbase,
                                                  uint32_t* __restrict__ tcount,
                                                  unsigned long long* __restrict__ counters) {
   __shared__ uint32_t s_wsum[TILE / 64];
+  __shared__ unsigned long long s_base;
   __shared__ uint4 s_stage[TILE * EXP_STAGE];  // first EXP_STAGE survivors of each thread
   const int rw = RW ? RW : rw_rt;
+  const bool has_m = rdm != nullptr;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
-  unsigned long long nvalid = 0, npair = 0;
+  unsigned long long nvalid = 0, npair = 0, ncand = 0;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t i = tile * TILE + threadIdx.x;
     const bool active = i < n;
+    const uint64_t r = r0 + (active ? i : 0);
     Rec<RW> rec;
-    rec.load(rd + (r0 + (active ? i : 0)) * (uint64_t)rw, rw);
+    rec.load(rd + r * (uint64_t)rw, rw);
+    Rec<RW> recm = rec;  // placeholder, only read under has_m
+    if (has_m) recm.load(rdm + r * (uint64_t)rw, rw);
     const int len = (int)rec.len();
     const uint32_t budget = nmiss_tab[len];
-    uint32_t valid = 0;
-    if (active)
-      for (int k = 0; k < pp.W; k++) valid |= (wsc[(uint64_t)i * pp.W + k].y >> 31) << k;
-    nvalid += __popc(valid);
 
-    // survivors: bit `ord` of surv for the ord-th entry of the read (first 64), count in cnt
-    auto walk = [&](bool write, uint64_t surv, uint64_t out) -> uint64_t {
-      uint32_t ord = 0, cnt = 0;
-      uint64_t bits = 0;
+    uint32_t valid = 0, cnt = 0;
+    // walk(write = false): probe, test, stage the first survivors, count;
+    // walk(write = true): same walk, writing every survivor from desc[out]
+    auto walk = [&](bool write, uint64_t out) {
       for (int k = 0; k < pp.W; k++) {
-        const uint2 sc = wsc[(uint64_t)i * pp.W + k];
-        const uint32_t c = sc.y & ~WSC_VALID;
+        const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
+        bool part = (uint32_t)len >= q2;
+        if (part && pp.min_dinuc > 0) part = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
+        if (!write) wb[(uint64_t)i * pp.W + k] = WB_NONE;
+        if (!part) continue;
+        const uint32_t b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+        const Bucket* __restrict__ bk = T + b;
+        const uint4 hdr = *reinterpret_cast<const uint4*>(bk);  // count, cursor, ovf
+        const uint32_t c = hdr.x;
+        if (!write) {
+          valid |= 1u << k;
+          wb[(uint64_t)i * pp.W + k] = b;
+          ncand += c;
+        }
         if (c == 0) continue;
-        const int q1 = pp.win[k], q2 = q1 + pp.ww;
-        const int nl = q1 < 8 ? q1 : 8;                                   // bases left of the window
-        const int nr = len - q2 < 8 ? (len - q2 < 0 ? 0 : len - q2) : 8;  // bases right of it
-        const uint32_t rfl = rec_flank_left(rec, (uint32_t)q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+        const uint64_t ovf = (uint64_t)hdr.z | ((uint64_t)hdr.w << 32);
+        // the read's own flanks and which of their bases exist
+        const int nl = q1 < 8 ? (int)q1 : 8;                                                // left of the window
+        const int nr = len - (int)q2 < 8 ? (len - (int)q2 < 0 ? 0 : len - (int)q2) : 8;     // right of it
+        const uint32_t rfl = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
         const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
                                ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
-        for (uint32_t e = 0; e < c; e++, ord++) {
-          if (write && ord < 64 && !((surv >> ord) & 1ull)) continue;
-          const uint4 ent = entries[(uint64_t)sc.x + e];
+        for (uint32_t e = 0; e < c; e++) {
+          const uint4 ent = e < BUCKET_INLINE ? bk->e[e] : E[ovf + (e - BUCKET_INLINE)];
           const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
           int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
           const int tcap = left + right;  // target length, saturated (exact below 65535)
           if (lim0 > tcap) lim0 = tcap;
           const bool fit0 = len <= lim0;
-          bool ok = q1 <= left;                 // p = jx - q1 >= 0
-          if (left == 0) ok = ok && fit0;       // window at target position 0: pos-0 path
-          else ok = ok && (len - q1 <= right);  // p + len <= T
+          bool ok = (int)q1 <= left;                 // p = jx - q1 >= 0
+          if (left == 0) ok = ok && fit0;            // window at target position 0: pos-0 path
+          else ok = ok && (len - (int)q1 <= right);  // p + len <= T
           const uint32_t x = rfl ^ ent.w;
           const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
           ok = ok && ((uint32_t)__popc(d) <= budget);
-          if (ok) {
-            const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
-            const uint32_t pos_ok = left < 65535 ? 1u : 0u;
-            const uint4 dd = make_uint4(i, ent.y - (uint32_t)q1,
-                                        (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
-            if (write) desc[out++] = dd;
-            else if (cnt < EXP_STAGE) s_stage[threadIdx.x * EXP_STAGE + cnt] = dd;
-          }
-          if (!write) {
-            if (ord < 64) bits |= (uint64_t)ok << ord;
-            cnt += ok;
+          if (!ok) continue;
+          const uint32_t z = (left == (int)q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
+          const uint32_t pos_ok = left < 65535 ? 1u : 0u;
+          const uint4 dd = make_uint4(i, ent.y - q1,
+                                      (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - (int)q1) << 6), ent.x);
+          if (write) {
+            desc[out++] = dd;
+          } else {
+            if (cnt < EXP_STAGE) s_stage[threadIdx.x * EXP_STAGE + cnt] = dd;
+            cnt++;
           }
         }
       }
-      (void)cnt;
-      return write ? out : bits;
     };
-    // (in count mode the lambda returns the survivor bits of the first 64 entries)
-    uint64_t surv = 0;
-    uint32_t cnt = 0;
-    if (active) {
-      surv = walk(false, 0, 0);
-      cnt = (uint32_t)__popcll(surv);
-      uint32_t tot = 0;
-      for (int k = 0; k < pp.W; k++) tot += wsc[(uint64_t)i * pp.W + k].y & ~WSC_VALID;
-      if (tot > 64) {  // rare: count the survivors beyond the 64 tracked ones exactly
-        uint32_t ord = 0, extra = 0;
-        for (int k = 0; k < pp.W; k++) {
-          const uint2 sc = wsc[(uint64_t)i * pp.W + k];
-          const uint32_t c = sc.y & ~WSC_VALID;
-          const int q1 = pp.win[k], q2 = q1 + pp.ww;
-          const int nl = q1 < 8 ? q1 : 8;
-          const int nr = len - q2 < 8 ? (len - q2 < 0 ? 0 : len - q2) : 8;
-          const uint32_t rfl = rec_flank_left(rec, (uint32_t)q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
-          const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
-                                 ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
-          for (uint32_t e = 0; e < c; e++, ord++) {
-            if (ord < 64) continue;
-            const uint4 ent = entries[(uint64_t)sc.x + e];
-            const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
-            int lim0 = 100 - pp.ww;
-            const int tcap = left + right;
-            if (lim0 > tcap) lim0 = tcap;
-            const bool fit0 = len <= lim0;
-            bool ok = q1 <= left;
-            if (left == 0) ok = ok && fit0; else ok = ok && (len - q1 <= right);
-            const uint32_t x = rfl ^ ent.w;
-            ok = ok && ((uint32_t)__popc((x | (x >> 1)) & 0x55555555u & fmask) <= budget);
-            extra += ok;
-          }
-        }
-        cnt += extra;
-      }
-    }
+    if (active) walk(false, 0);
+    nvalid += __popc(valid);
+
     // workgroup exclusive scan of cnt
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t inc = cnt;
@@ -641,7 +610,7 @@ __global__ __launch_bounds__(TILE) void k_expand(const uint32_t* __restrict__ rd
       const uint32_t o = __shfl_up(inc, d);
       if (lane >= d) inc += o;
     }
-    __syncthreads();  // previous iteration's readers of s_wsum are done
+    __syncthreads();  // the previous tile's readers of s_wsum / s_base are done
     if (lane == 63) s_wsum[wid] = inc;
     __syncthreads();
     uint32_t woff = 0, total = 0;
@@ -650,22 +619,31 @@ __global__ __launch_bounds__(TILE) void k_expand(const uint32_t* __restrict__ rd
       if (w < wid) woff += s_wsum[w];
       total += s_wsum[w];
     }
-    const uint32_t tbase = rbase[tile * TILE];
-    const uint32_t mine = tbase + woff + inc - cnt;
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[7], (unsigned long long)total) : 0ull;
+    __syncthreads();
+    const unsigned long long base = s_base;
+    const bool fits = base + total <= desc_cap;  // else: the host grows desc and repeats the batch
+    const uint32_t mine = (uint32_t)base + woff + inc - cnt;
     if (active) {
       cbase[i] = mine;
-      vcnt[i] = cnt;
+      vcnt[i] = fits ? cnt : 0u;
       rvalid[i] = valid;
-      if (cnt <= EXP_STAGE) {
-        for (uint32_t q = 0; q < cnt; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
-      } else {
-        walk(true, surv, mine);
+      if (fits) {
+        if (cnt <= EXP_STAGE) {
+          for (uint32_t q = 0; q < cnt; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
+        } else {
+          walk(true, mine);
+        }
       }
       npair += cnt;
     }
-    if (threadIdx.x == 0) tcount[tile] = total;
+    if (threadIdx.x == 0) {
+      tbase[tile] = (uint32_t)base;
+      tcount[tile] = fits ? total : 0u;
+    }
   }
   block_add_u64(nvalid, &counters[0]);
+  block_add_u64(ncand, &counters[3]);
   block_add_u64(npair, &counters[4]);
 }
 
@@ -692,18 +670,17 @@ struct __attribute__((packed, aligned(4))) u32x4_u {
 // whether THIS window is the first window of the read that the reference would have emitted
 // the tuple through (exact window key + fit), which makes the union over windows a set
 // without a sort.  RW = record words (compile time) or 0 = runtime stride.  One workgroup per
-// tile of k_expand: its pairs are desc[rbase[tile*256] .. +tcount[tile]), counts stay on the
-// device so no host round trip sits in front of the launch.
+// tile of k_screen: its pairs are desc[tbase[tile] .. +tcount[tile]).
 template <int RW, bool MASK>
 __global__ __launch_bounds__(256) void k_confirm(
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
     const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, int rw_rt,
     PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
     const uint32_t* __restrict__ rvalid, uint32_t* __restrict__ p_nx,
-    const uint32_t* __restrict__ rbase, const uint32_t* __restrict__ tcount) {
+    const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ tcount) {
   const uint32_t tile = blockIdx.x;
   const uint32_t tn = tcount[tile];
-  const uint64_t tb = rbase[tile * TILE];
+  const uint64_t tb = tbase[tile];
   for (uint32_t tj = threadIdx.x; tj < tn; tj += blockDim.x) {
   const uint64_t idx = tb + tj;
   // descriptors, read records and results stream through once: non-temporal, so that the
@@ -801,7 +778,7 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
                                                     const uint32_t* __restrict__ cbase,
                                                     const uint32_t* __restrict__ vcnt,
                                                     const uint32_t* __restrict__ p_nx,
-                                                    const uint2* __restrict__ wsc, int block_mode,
+                                                    const uint32_t* __restrict__ wb, int block_mode,
                                                     uint32_t block_thr,
                                                     uint32_t* __restrict__ block_table,
                                                     uint32_t* __restrict__ hcnt,
@@ -818,7 +795,7 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
     uint32_t best = 0xFFFFFFFFu, na = 0, nbest = 0;
     // a read's pairs are stored window-major: count the pairs each window's confirm accepts
     // and add them to that (window, key) block (cmd/muscato_confirm/main.go:233-242, 424-448
-    // truncate a block at MaxMatches).  The bucket start identifies the key.
+    // truncate a block at MaxMatches).  The index bucket identifies the key.
     // per-window accepted counts, 8 bits each (windows 0-7 in wc0, 8-15 in wc1); a count
     // that would pass 255 raises the "hot" flag instead (=> exact pass)
     uint64_t wc0 = 0, wc1 = 0;
@@ -844,14 +821,14 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
         const uint32_t w = p_nx[j];
         if (w == NX_REJECT) continue;
         const uint32_t k = w >> 20;
-        const uint64_t h = mix64(((uint64_t)k << 32) | wsc[(uint64_t)i * pp.W + k].x);
+        const uint64_t h = mix64(((uint64_t)k << 32) | wb[(uint64_t)i * pp.W + k]);
         atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], 1u);
       }
     } else if (block_mode) {
       for (int k = 0; k < pp.W; k++) {  // uniform loop: the atomics of a wave issue together
         const uint32_t cw = (uint32_t)(((k < 8 ? wc0 : wc1) >> ((k & 7) * 8)) & 0xFFull);
         if (cw) {
-          const uint64_t h = mix64(((uint64_t)k << 32) | wsc[(uint64_t)i * pp.W + k].x);
+          const uint64_t h = mix64(((uint64_t)k << 32) | wb[(uint64_t)i * pp.W + k]);
           if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - BLOCK_LDS_BITS)], cw);
           else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
         }
@@ -972,9 +949,10 @@ struct musc_ctx {
 
   // index
   int idx_ww = 0, idx_bits = 0, idx_direct = 0;
-  uint32_t* idx_A = nullptr;
-  uint4* idx_entries = nullptr;
-  uint64_t idx_n = 0;
+  Bucket* idx_T = nullptr;  // 2^idx_bits buckets
+  uint4* idx_E = nullptr;   // overflow entries
+  uint64_t idx_n = 0;       // indexed window starts
+  uint64_t idx_novf = 0;
 
   // reads
   uint32_t* rd = nullptr;
@@ -984,8 +962,7 @@ struct musc_ctx {
   uint32_t max_len = 0;
 
   // per-batch work buffers
-  DevBuf<uint2> wsc;
-  DevBuf<uint32_t> rtot, rbase, vcnt, cbase, rvalid, tcount, scan_tmp, hcnt, hbase, hthr;
+  DevBuf<uint32_t> wb, vcnt, cbase, rvalid, tbase, tcount, scan_tmp, hcnt, hbase, hthr;
   DevBuf<uint4> cdesc;
   DevBuf<uint32_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
@@ -1074,10 +1051,10 @@ int scan_u32(musc_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, bool in
 }
 
 void free_index(musc_ctx* c) {
-  if (c->idx_A) (void)hipFree(c->idx_A);
-  if (c->idx_entries) (void)hipFree(c->idx_entries);
-  c->idx_A = nullptr;
-  c->idx_entries = nullptr;
+  if (c->idx_T) (void)hipFree(c->idx_T);
+  if (c->idx_E) (void)hipFree(c->idx_E);
+  c->idx_T = nullptr;
+  c->idx_E = nullptr;
   c->idx_ww = 0;
   c->idx_n = 0;
 }
@@ -1149,34 +1126,30 @@ int check_params(musc_ctx* c, const musc_params* P) {
 }
 
 template <int RW>
-void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp, uint64_t slots) {
-  const dim3 block(256), rgrid(std::min(nblk(n, 256), MAX_GRID));
+void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp) {
+  const dim3 block(TILE);
   if (stage == 0) {
-    hipLaunchKernelGGL((k_seed<RW>), rgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp, c->idx_A,
-                       c->wsc.p, c->rtot.p, c->counters);
-  } else if (stage == 1) {
-    hipLaunchKernelGGL((k_expand<RW>), rgrid, block, 0, c->stream, c->rd, r0, n, c->rw, pp, c->nmiss_tab.p,
-                       c->wsc.p, c->rbase.p, c->idx_entries, c->cdesc.p, c->cbase.p, c->vcnt.p, c->rvalid.p,
-                       c->tcount.p, c->counters);
+    hipLaunchKernelGGL((k_screen<RW>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd, c->rdm, r0,
+                       n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap, c->cbase.p,
+                       c->vcnt.p, c->rvalid.p, c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
   } else {
-    const dim3 grid(nblk(n, TILE));  // one workgroup per k_expand tile
-    (void)slots;
+    const dim3 grid(nblk(n, TILE));  // one workgroup per k_screen tile
     if (mask)
       hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->rbase.p, c->tcount.p);
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p);
     else
       hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->rbase.p, c->tcount.p);
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p);
   }
 }
 
-void launch_stage(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp, uint64_t slots) {
+void launch_stage(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp) {
   switch (c->rw) {
-    case 4: launch_path<4>(c, stage, mask, r0, n, pp, slots); break;
-    case 8: launch_path<8>(c, stage, mask, r0, n, pp, slots); break;
-    case 12: launch_path<12>(c, stage, mask, r0, n, pp, slots); break;
-    case 16: launch_path<16>(c, stage, mask, r0, n, pp, slots); break;
-    default: launch_path<0>(c, stage, mask, r0, n, pp, slots); break;
+    case 4: launch_path<4>(c, stage, mask, r0, n, pp); break;
+    case 8: launch_path<8>(c, stage, mask, r0, n, pp); break;
+    case 12: launch_path<12>(c, stage, mask, r0, n, pp); break;
+    case 16: launch_path<16>(c, stage, mask, r0, n, pp); break;
+    default: launch_path<0>(c, stage, mask, r0, n, pp); break;
   }
 }
 
@@ -1210,8 +1183,8 @@ int musc_init(int device_ordinal, musc_ctx** out) {
   c->device = device_ordinal;
   memset(&c->stats, 0, sizeof c->stats);
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipMalloc((void**)&c->counters, 8 * sizeof(unsigned long long))) != hipSuccess ||
-      (e = hipHostMalloc((void**)&c->h_pinned, 8 * sizeof(uint64_t))) != hipSuccess) {
+      (e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(uint64_t))) != hipSuccess) {
     fail(nullptr, 3, "musc_init: %s", hipGetErrorString(e));
     musc_destroy(c);
     return 3;
@@ -1226,7 +1199,7 @@ void musc_destroy(musc_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_db(c);
   free_reads(c);
-  c->wsc.release(); c->rtot.release(); c->rbase.release(); c->vcnt.release(); c->cbase.release();
+  c->wb.release(); c->tbase.release(); c->vcnt.release(); c->cbase.release();
   c->scan_tmp.release(); c->hcnt.release(); c->hbase.release(); c->hthr.release();
   c->rvalid.release(); c->tcount.release(); c->cdesc.release(); c->p_nx.release();
   c->nmiss_tab.release();
@@ -1339,47 +1312,56 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   if (!c->db2) return fail(c, 4, "no database loaded");
   if (ww < 1 || ww > 4096) return fail(c, 2, "bad window width %d", ww);
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->idx_ww == ww && c->idx_A) return 0;
+  if (c->idx_ww == ww && c->idx_T) return 0;
   free_index(c);
-  // number of indexed window starts is at most nbases
   if (c->nbases >= 0xFFFFFFF0ull)
-    return fail(c, 5, "database of %llu bases exceeds the 32-bit index offsets of this build",
+    return fail(c, 5, "database of %llu bases exceeds the 32-bit positions of this build",
                 (unsigned long long)c->nbases);
-  // Direct addressing (bucket = the 2*ww-bit key itself, exact) when the table is small or
-  // not much sparser than the database; otherwise a hashed table of >= 4 buckets per base.
+  // Direct addressing (bucket = the 2*ww-bit key itself: exact, and bytewise-sorted reads walk
+  // the table front to back) when that table is at most 32x the database and at most 2^30
+  // buckets (64 GiB); otherwise a hashed table with about one bucket per base.
   int bits, direct = 0;
-  if (2 * ww <= 32 && ((1ull << (2 * ww)) <= (1ull << 24) || (1ull << (2 * ww)) <= 64 * c->nbases)) {
+  const uint64_t floor_bases = std::max<uint64_t>(c->nbases, 1ull << 19);
+  if (2 * ww <= 30 && (1ull << (2 * ww)) <= 32 * floor_bases) {
     bits = 2 * ww;
     direct = 1;
   } else {
-    bits = 20;
-    while (bits < 32 && (1ull << bits) < 4 * c->nbases) bits++;
+    bits = 10;
+    while (bits < 30 && (1ull << bits) < c->nbases) bits++;
   }
   const uint64_t nb = 1ull << bits;
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
   HIPCHK(c, hipEventRecord(e0, c->stream));
-  HIPCHK(c, hipMalloc((void**)&c->idx_A, (nb + 2 + 64) * 4));
-  HIPCHK(c, hipMemsetAsync(c->idx_A, 0, (nb + 2 + 64) * 4, c->stream));
+  HIPCHK(c, hipMalloc((void**)&c->idx_T, (nb + 1) * sizeof(Bucket)));
+  HIPCHK(c, hipMemsetAsync(c->idx_T, 0, (nb + 1) * sizeof(Bucket), c->stream));
   const unsigned blocks = nblk(c->nbases, 256);
   if (c->nbases) {
     hipLaunchKernelGGL(k_index<false>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
-                       c->nbases, ww, bits, direct, c->idx_A, (uint4*)nullptr);
+                       c->nbases, ww, bits, direct, c->idx_T, (uint4*)nullptr);
     HIPCHK(c, hipGetLastError());
   }
-  int rc = ensure(c, c->scan_tmp, scan_tmp_elems(nb + 2));
+  // overflow lists: sizes -> offsets
+  uint32_t* tmp = nullptr;
+  HIPCHK(c, hipMalloc((void**)&tmp, (nb + 1 + 16) * 4));
+  hipLaunchKernelGGL(k_index_ovf_count, dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
+  HIPCHK(c, hipGetLastError());
+  int rc = ensure(c, c->scan_tmp, scan_tmp_elems(nb + 1));
   if (rc) return rc;
-  rc = scan_u32(c, c->idx_A, c->idx_A, nb + 2, true, c->scan_tmp.p);
+  rc = scan_u32(c, tmp, tmp, nb + 1, false, c->scan_tmp.p);
   if (rc) return rc;
-  uint32_t total = 0;
-  HIPCHK(c, hipMemcpyAsync(&total, c->idx_A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream));
+  uint32_t novf = 0;
+  HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 4, hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_index_ovf_set, dim3(nblk(nb, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->idx_n = total;
-  HIPCHK(c, hipMalloc((void**)&c->idx_entries, ((uint64_t)total + 16) * sizeof(uint4)));
+  (void)hipFree(tmp);
+  c->idx_novf = novf;
+  HIPCHK(c, hipMalloc((void**)&c->idx_E, ((uint64_t)novf + 16) * sizeof(uint4)));
   if (c->nbases) {
     hipLaunchKernelGGL(k_index<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
-                       c->nbases, ww, bits, direct, c->idx_A, c->idx_entries);
+                       c->nbases, ww, bits, direct, c->idx_T, c->idx_E);
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipEventRecord(e1, c->stream));
@@ -1573,71 +1555,74 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipMemsetAsync(c->dbm2, 0, (c->db_words + 64) * 4, c->stream));
   }
 
-  uint64_t n_slots = 0;  // candidate slots incl. the ones k_expand rejected
-  const uint64_t PAIR_CAP = 1ull << 30;  // pairs per batch (19 B of work buffers each)
+  // Per batch: k_screen claims descriptor space as it goes; if a batch needs more than the
+  // buffer holds it reports how much and is repeated after growing the buffer (the first pass
+  // of a workload sizes it; steady-state passes never repeat).
+  uint64_t n_cand = 0, n_pairs = 0, n_windows = 0;
+  const uint64_t PAIR_CAP = 1ull << 31;  // u32 descriptor offsets
   uint64_t r0 = 0;
   uint32_t bsz = c->batch_reads;
   while (r0 < c->nreads) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
     const int W = pp.W;
-    if ((rc = ensure(c, c->wsc, (uint64_t)n * W))) return rc;
-    if ((rc = ensure(c, c->rtot, (uint64_t)n + 1))) return rc;
-    if ((rc = ensure(c, c->rbase, (uint64_t)n + 1))) return rc;
+    const uint32_t ntiles = nblk(n, TILE);
+    if ((rc = ensure(c, c->wb, (uint64_t)n * W))) return rc;
     if ((rc = ensure(c, c->vcnt, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->cbase, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->rvalid, (uint64_t)n + 1))) return rc;
-    if ((rc = ensure(c, c->tcount, (uint64_t)nblk(n, TILE) + 1))) return rc;
+    if ((rc = ensure(c, c->tbase, (uint64_t)ntiles + 1))) return rc;
+    if ((rc = ensure(c, c->tcount, (uint64_t)ntiles + 1))) return rc;
     if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)n + 1)))) return rc;
     if ((rc = ensure(c, c->hcnt, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->hbase, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->hthr, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->cdesc, std::max<uint64_t>(4ull * n, 1024)))) return rc;
 
     tm.begin(0);
-    HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->rtot.p + n, 0, 4, c->stream));
-    launch_stage(c, 0, mask, r0, n, pp, 0);
+    // batch-local counters: [0] valid windows [3] candidates [4] pairs [7] descriptor cursor
+    HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
+    launch_stage(c, 0, mask, r0, n, pp);
     HIPCHK(c, hipGetLastError());
     tm.end(0);
-    tm.begin(1);
-    rc = scan_u32(c, c->rtot.p, c->rbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
-    if (rc) return rc;
-    tm.end(1);
-    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 3, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[1], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 8, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[8], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const uint64_t total = c->h_pinned[0];  // candidate slots of this batch
-    const uint64_t hits_so_far = c->h_pinned[1];
+    const uint64_t total = c->h_pinned[7];  // pairs of this batch
+    const uint64_t hits_so_far = c->h_pinned[8];
     if (total > PAIR_CAP) {
-      // too many candidates for one launch: retry this range with half the reads
-      if (n == 1) return fail(c, 6, "one read has %llu candidate pairs (> 2^30)", (unsigned long long)total);
+      // too many pairs for one launch: retry this range with half the reads
+      if (n == 1) return fail(c, 6, "one read has %llu candidate pairs (> 2^31)", (unsigned long long)total);
       bsz = n / 2;
       continue;
     }
+    if (total > c->cdesc.cap) {
+      if ((rc = ensure(c, c->cdesc, total + total / 8))) return rc;
+      continue;  // repeat the batch with room for every pair
+    }
     c->stats.n_batches++;
-    n_slots += total;
-    if ((rc = ensure(c, c->cdesc, total))) return rc;
+    n_windows += c->h_pinned[0];
+    n_cand += c->h_pinned[3];
+    n_pairs += c->h_pinned[4];
     if ((rc = ensure(c, c->p_nx, total))) return rc;
     if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
 
-    tm.begin(2);
-    launch_stage(c, 1, mask, r0, n, pp, 0);
-    HIPCHK(c, hipGetLastError());
-    tm.end(2);
     if (total) {
       const dim3 sg(std::min(nblk(n, 256), MAX_GRID));
 
       tm.begin(3);
-      launch_stage(c, 2, mask, r0, n, pp, total);
+      launch_stage(c, 2, mask, r0, n, pp);
       HIPCHK(c, hipGetLastError());
       tm.end(3);
       c->stats.confirm_launches++;
 
       tm.begin(4);
       hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->cbase.p, c->vcnt.p, c->p_nx.p,
-                         c->wsc.p, block_mode, block_thr, c->block_table.p, c->hcnt.p, c->hthr.p, c->counters);
+                         c->wb.p, block_mode, block_thr, c->block_table.p, c->hcnt.p, c->hthr.p, c->counters);
       HIPCHK(c, hipGetLastError());
+      tm.begin(1);
       rc = scan_u32(c, c->hcnt.p, c->hbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
       if (rc) return rc;
+      tm.end(1);
       hipLaunchKernelGGL(k_emit, sg, dim3(256), 0, c->stream, r0, n, c->cbase.p, c->vcnt.p, c->hbase.p, c->hthr.p, c->cdesc.p,
                          c->p_nx.p, c->seq_off, c->hits.p, c->counters);
       HIPCHK(c, hipGetLastError());
@@ -1655,11 +1640,11 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   HIPCHK(c, hipEventRecord(ev1, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 7 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->stats.n_read_windows = c->h_pinned[0];
+  c->stats.n_read_windows = n_windows;
   c->stats.n_accepted = c->h_pinned[1];
   c->stats.n_hits = c->nhits = c->h_pinned[2];
-  c->stats.n_pairs = c->h_pinned[4];
-  c->stats.n_candidates = n_slots;
+  c->stats.n_pairs = n_pairs;
+  c->stats.n_candidates = n_cand;
   // 0 = proven: no (window,key) block exceeded MaxMatches, the tuples equal the reference's;
   // otherwise an upper bound on the number of such blocks (or ~0ull when the check was skipped)
   c->stats.n_overflow_blocks = check_blocks ? c->h_pinned[5] : ~0ull;
