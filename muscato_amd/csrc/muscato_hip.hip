@@ -487,6 +487,7 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 
 #define TILE 256  // reads per tile = threads per workgroup of k_screen
 #define EXP_STAGE 4
+#define EXP_POOL 256
 
 // k_screen -- muscato_screen + the join, fused: one workgroup per tile of 256 reads, one
 // thread per read.  For each window of the read that takes part
@@ -530,6 +531,10 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
   __shared__ uint32_t s_wsum[TILE / 64];
   __shared__ unsigned long long s_base;
   __shared__ uint4 s_stage[TILE * EXP_STAGE];  // first EXP_STAGE survivors of each thread
+  __shared__ uint4 s_pool[EXP_POOL];           // the tile's survivors beyond that, any thread
+  __shared__ uint32_t s_ptag[EXP_POOL];        // owner thread << 16 | ordinal within the read
+  __shared__ uint32_t s_mine[TILE];
+  __shared__ uint32_t s_pooln;
   const int rw = RW ? RW : rw_rt;
   const bool has_m = rdm != nullptr;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -546,6 +551,9 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
     const uint32_t budget = nmiss_tab[len];
 
     uint32_t valid = 0, cnt = 0;
+    bool rewalk = false;  // the pool was full: this read writes its survivors in a second walk
+    if (threadIdx.x == 0) s_pooln = 0;
+    __syncthreads();  // also: the previous tile's pool readers are done
     // walk(write = false): probe, test, stage the first survivors, count;
     // walk(write = true): same walk, writing every survivor from desc[out]
     auto walk = [&](bool write, uint64_t out) {
@@ -573,7 +581,8 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
         const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
                                ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
         for (uint32_t e = 0; e < c; e++) {
-          const uint4 ent = e < BUCKET_INLINE ? bk->e[e] : E[ovf + (e - BUCKET_INLINE)];
+          const uint4* __restrict__ ep = e < BUCKET_INLINE ? &bk->e[e] : &E[ovf + (e - BUCKET_INLINE)];
+          const uint4 ent = *ep;
           const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
           int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
           const int tcap = left + right;  // target length, saturated (exact below 65535)
@@ -593,7 +602,17 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
           if (write) {
             desc[out++] = dd;
           } else {
-            if (cnt < EXP_STAGE) s_stage[threadIdx.x * EXP_STAGE + cnt] = dd;
+            if (cnt < EXP_STAGE) {
+              s_stage[threadIdx.x * EXP_STAGE + cnt] = dd;
+            } else if (!rewalk) {
+              const uint32_t slot = atomicAdd(&s_pooln, 1u);
+              if (slot < EXP_POOL) {
+                s_pool[slot] = dd;
+                s_ptag[slot] = (threadIdx.x << 16) | (cnt & 0xFFFFu);
+              } else {
+                rewalk = true;
+              }
+            }
             cnt++;
           }
         }
@@ -624,18 +643,30 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
     const unsigned long long base = s_base;
     const bool fits = base + total <= desc_cap;  // else: the host grows desc and repeats the batch
     const uint32_t mine = (uint32_t)base + woff + inc - cnt;
+    rewalk = rewalk || cnt > 0xFFFFu;  // ordinals in the pool tags are 16 bits
+    s_mine[threadIdx.x] = rewalk ? 0xFFFFFFFFu : mine;
     if (active) {
       cbase[i] = mine;
       vcnt[i] = fits ? cnt : 0u;
       rvalid[i] = valid;
       if (fits) {
-        if (cnt <= EXP_STAGE) {
-          for (uint32_t q = 0; q < cnt; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
-        } else {
+        if (rewalk) {
           walk(true, mine);
+        } else {
+          const uint32_t ns = cnt < EXP_STAGE ? cnt : EXP_STAGE;
+          for (uint32_t q = 0; q < ns; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
         }
       }
       npair += cnt;
+    }
+    __syncthreads();  // s_mine and the pool are complete
+    if (fits) {
+      const uint32_t pn = s_pooln < EXP_POOL ? s_pooln : EXP_POOL;
+      for (uint32_t q = threadIdx.x; q < pn; q += TILE) {
+        const uint32_t tag = s_ptag[q];
+        const uint32_t m = s_mine[tag >> 16];
+        if (m != 0xFFFFFFFFu) desc[m + (tag & 0xFFFFu)] = s_pool[q];
+      }
     }
     if (threadIdx.x == 0) {
       tbase[tile] = (uint32_t)base;
