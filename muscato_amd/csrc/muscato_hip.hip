@@ -502,17 +502,18 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // k-mer hits are about half of all candidates).  The flank test never over-counts: an X is
 // stored as code 0 on both sides.
 //
-// Survivors: the first 4 descriptors of a thread wait in LDS; after a workgroup scan of the
-// counts the tile claims a contiguous range of `desc` with one atomic and the threads copy
-// their descriptors in read order (a read with more survivors walks its buckets again).  A
-// tile's pairs are contiguous and a read's pairs adjacent, window-major; tile ranges are in
-// arrival order, which nothing downstream depends on (k_emit orders the tuples by read).
+// Survivors: the first 4 descriptors of a thread wait in LDS (a shared pool takes the rest);
+// after a workgroup scan of the counts the tile takes the next range of its workgroup's own
+// region of `desc` (region = desc_cap / gridDim descriptors: no atomics -- one shared cursor
+// would serialise ~60 k single-address atomics per launch at ~11 ns each) and the threads copy
+// their descriptors in read order.  A tile's pairs are contiguous, a read's pairs adjacent;
+// nothing downstream depends on where a tile's range lies (k_emit orders the tuples by read).
 //
 // Descriptor (16 B): x = read index within the batch, y = global base offset of the
 // placement, z = window | z-flag << 4 | pos_ok << 5 | position in the target << 6 (when it
 // fits 16 bits exactly), w = gene.
 // counters: [0] valid windows, [3] candidates (index entries walked), [4] pairs,
-//           [7] desc cursor (also the number of pairs the batch needs).
+//           [7] the largest number of descriptors any workgroup needed (region size to retry with).
 template <int RW>
 __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd,
                                                  const uint32_t* __restrict__ rdm, uint64_t r0,
@@ -529,7 +530,6 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
                                                  uint32_t* __restrict__ tcount,
                                                  unsigned long long* __restrict__ counters) {
   __shared__ uint32_t s_wsum[TILE / 64];
-  __shared__ unsigned long long s_base;
   __shared__ uint4 s_stage[TILE * EXP_STAGE];  // first EXP_STAGE survivors of each thread
   __shared__ uint4 s_pool[EXP_POOL];           // the tile's survivors beyond that, any thread
   __shared__ uint32_t s_ptag[EXP_POOL];        // owner thread << 16 | ordinal within the read
@@ -539,6 +539,9 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
   const bool has_m = rdm != nullptr;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
   unsigned long long nvalid = 0, npair = 0, ncand = 0;
+  const uint64_t region = desc_cap / gridDim.x;
+  const uint64_t region0 = region * blockIdx.x;
+  uint64_t used = 0;  // descriptors this workgroup has needed so far (uniform across the workgroup)
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t i = tile * TILE + threadIdx.x;
     const bool active = i < n;
@@ -638,10 +641,9 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
       if (w < wid) woff += s_wsum[w];
       total += s_wsum[w];
     }
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(&counters[7], (unsigned long long)total) : 0ull;
-    __syncthreads();
-    const unsigned long long base = s_base;
-    const bool fits = base + total <= desc_cap;  // else: the host grows desc and repeats the batch
+    const unsigned long long base = region0 + used;
+    const bool fits = used + total <= region;  // else: the host grows desc and repeats the batch
+    used += total;
     const uint32_t mine = (uint32_t)base + woff + inc - cnt;
     rewalk = rewalk || cnt > 0xFFFFu;  // ordinals in the pool tags are 16 bits
     s_mine[threadIdx.x] = rewalk ? 0xFFFFFFFFu : mine;
@@ -676,6 +678,7 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
   block_add_u64(nvalid, &counters[0]);
   block_add_u64(ncand, &counters[3]);
   block_add_u64(npair, &counters[4]);
+  if (threadIdx.x == 0) atomicMax(&counters[7], (unsigned long long)used);
 }
 
 // u32 mask of the bits of window [q1, q1+ww) (2 bits per base) that fall in record word j
@@ -1360,6 +1363,10 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
     bits = 10;
     while (bits < 30 && (1ull << bits) < c->nbases) bits++;
   }
+  if (const char* ov = getenv("MUSC_DEBUG_INDEX_BITS")) {  // experiments only: force a hashed table size
+    const int v = atoi(ov);
+    if (v >= 8 && v <= 30) { bits = v; direct = 0; }
+  }
   const uint64_t nb = 1ull << bits;
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
@@ -1618,23 +1625,25 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 8, 8 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&c->h_pinned[8], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const uint64_t total = c->h_pinned[7];  // pairs of this batch
+    const uint64_t total = c->h_pinned[4];  // pairs of this batch
     const uint64_t hits_so_far = c->h_pinned[8];
-    if (total > PAIR_CAP) {
+    const uint64_t sgrid = std::min(nblk(n, TILE), MAX_GRID);
+    const uint64_t need = c->h_pinned[7] * sgrid;  // every workgroup region as large as the fullest
+    if (need > PAIR_CAP) {
       // too many pairs for one launch: retry this range with half the reads
       if (n == 1) return fail(c, 6, "one read has %llu candidate pairs (> 2^31)", (unsigned long long)total);
       bsz = n / 2;
       continue;
     }
-    if (total > c->cdesc.cap) {
-      if ((rc = ensure(c, c->cdesc, total + total / 8))) return rc;
-      continue;  // repeat the batch with room for every pair
+    if (c->h_pinned[7] > c->cdesc.cap / sgrid) {
+      if ((rc = ensure(c, c->cdesc, need + need / 8 + sgrid))) return rc;
+      continue;  // repeat the batch with room for every workgroup's pairs
     }
     c->stats.n_batches++;
     n_windows += c->h_pinned[0];
     n_cand += c->h_pinned[3];
     n_pairs += c->h_pinned[4];
-    if ((rc = ensure(c, c->p_nx, total))) return rc;
+    if ((rc = ensure(c, c->p_nx, c->cdesc.cap))) return rc;
     if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
 
     if (total) {
