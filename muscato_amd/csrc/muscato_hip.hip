@@ -514,6 +514,20 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // fits 16 bits exactly), w = gene.
 // counters: [0] valid windows, [3] candidates (index entries walked), [4] pairs,
 //           [7] the largest number of descriptors any workgroup needed (region size to retry with).
+#define SCR_OWN 2048  // flat items per chunk whose owner is looked up directly
+
+// context of one (read, window) probe while its bucket entries are being tested
+struct __attribute__((aligned(16))) ScrCtx {
+  uint32_t bucket;  // index into T
+  uint32_t ovf;     // start of the bucket's overflow list in E
+  uint32_t rfl;     // the read's own 8+8 flanking bases around this window
+  uint32_t fmask;   // which of them exist
+  uint32_t lenbud;  // read length | mismatch budget << 16
+  uint32_t kq1;     // window index | window start << 8
+  uint32_t owner;   // thread (= read of the tile)
+  uint32_t pad;
+};
+
 template <int RW>
 __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd,
                                                  const uint32_t* __restrict__ rdm, uint64_t r0,
@@ -529,19 +543,72 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
                                                  uint32_t* __restrict__ tbase,
                                                  uint32_t* __restrict__ tcount,
                                                  unsigned long long* __restrict__ counters) {
+  // The entries of a tile's buckets are tested as ONE flat list spread evenly over the 256
+  // threads (a (read, window) with c entries owns c consecutive items): every entry load is
+  // independent and they are issued together.  Walking each read's buckets in its own lane
+  // instead costs a dependent L2 round trip per entry, repeated max-over-lanes times with most
+  // lanes idle -- that chain, not bandwidth, bounded the kernel.
   __shared__ uint32_t s_wsum[TILE / 64];
-  __shared__ uint4 s_stage[TILE * EXP_STAGE];  // first EXP_STAGE survivors of each thread
-  __shared__ uint4 s_pool[EXP_POOL];           // the tile's survivors beyond that, any thread
+  __shared__ ScrCtx s_ctx[2 * TILE];           // two windows per chunk
+  __shared__ uint32_t s_pref[2 * TILE + 1];    // exclusive prefix of the entry counts
+  __shared__ uint16_t s_own[SCR_OWN];          // flat item -> context
+  __shared__ uint32_t s_cnt[TILE];             // survivors per read so far
+  __shared__ uint4 s_stage[TILE * EXP_STAGE];  // first EXP_STAGE survivors of each read
+  __shared__ uint4 s_pool[EXP_POOL];           // the tile's survivors beyond that, any read
   __shared__ uint32_t s_ptag[EXP_POOL];        // owner thread << 16 | ordinal within the read
   __shared__ uint32_t s_mine[TILE];
-  __shared__ uint32_t s_pooln;
+  __shared__ uint32_t s_pooln, s_lost;
   const int rw = RW ? RW : rw_rt;
   const bool has_m = rdm != nullptr;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   unsigned long long nvalid = 0, npair = 0, ncand = 0;
   const uint64_t region = desc_cap / gridDim.x;
   const uint64_t region0 = region * blockIdx.x;
   uint64_t used = 0;  // descriptors this workgroup has needed so far (uniform across the workgroup)
+
+  // workgroup exclusive scan helper: returns this thread's exclusive prefix, *total = sum
+  auto wg_scan = [&](uint32_t v, uint32_t* total) -> uint32_t {
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();  // earlier readers of s_wsum are done
+    if (lane == 63) s_wsum[wid] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < TILE / 64; w++) {
+      if (w < wid) woff += s_wsum[w];
+      tot += s_wsum[w];
+    }
+    *total = tot;
+    return woff + inc - v;
+  };
+
+  // one index entry against one (read, window) context: fit rules + flank filter
+  auto test_entry = [&](const uint4& ent, uint32_t owner_i, int k, int q1, int len, uint32_t budget,
+                        uint32_t rfl, uint32_t fmask, uint4* dd) -> bool {
+    const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
+    int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
+    const int tcap = left + right;  // target length, saturated (exact below 65535)
+    if (lim0 > tcap) lim0 = tcap;
+    const bool fit0 = len <= lim0;
+    bool ok = q1 <= left;                 // p = jx - q1 >= 0
+    if (left == 0) ok = ok && fit0;       // window at target position 0: pos-0 path
+    else ok = ok && (len - q1 <= right);  // p + len <= T
+    const uint32_t x = rfl ^ ent.w;
+    const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
+    ok = ok && ((uint32_t)__popc(d) <= budget);
+    const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
+    const uint32_t pos_ok = left < 65535 ? 1u : 0u;
+    *dd = make_uint4(owner_i, ent.y - (uint32_t)q1,
+                     (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
+    return ok;
+  };
+
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t i = tile * TILE + threadIdx.x;
     const bool active = i < n;
@@ -552,128 +619,153 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
     if (has_m) recm.load(rdm + r * (uint64_t)rw, rw);
     const int len = (int)rec.len();
     const uint32_t budget = nmiss_tab[len];
+    uint32_t valid = 0;
+    s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_pooln = 0; s_lost = 0; }
 
-    uint32_t valid = 0, cnt = 0;
-    bool rewalk = false;  // the pool was full: this read writes its survivors in a second walk
-    if (threadIdx.x == 0) s_pooln = 0;
-    __syncthreads();  // also: the previous tile's pool readers are done
-    // walk(write = false): probe, test, stage the first survivors, count;
-    // walk(write = true): same walk, writing every survivor from desc[out]
-    auto walk = [&](bool write, uint64_t out) {
-      for (int k = 0; k < pp.W; k++) {
-        const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
-        bool part = (uint32_t)len >= q2;
-        if (part && pp.min_dinuc > 0) part = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
-        if (!write) wb[(uint64_t)i * pp.W + k] = WB_NONE;
-        if (!part) continue;
-        const uint32_t b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
-        const Bucket* __restrict__ bk = T + b;
-        const uint4 hdr = *reinterpret_cast<const uint4*>(bk);  // count, cursor, ovf
-        const uint32_t c = hdr.x;
-        if (!write) {
+    auto window_bucket = [&](int k, uint32_t* b) -> bool {
+      const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
+      bool part = (uint32_t)len >= q2;
+      if (part && pp.min_dinuc > 0) part = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
+      if (part) *b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+      return part;
+    };
+    auto window_ctx = [&](int k, uint32_t b, uint32_t ovf, ScrCtx* cx) {
+      const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
+      const int nl = q1 < 8 ? (int)q1 : 8;                                             // left of the window
+      const int nr = len - (int)q2 < 8 ? (len - (int)q2 < 0 ? 0 : len - (int)q2) : 8;  // right of it
+      cx->bucket = b;
+      cx->ovf = ovf;
+      cx->rfl = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+      cx->fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) | ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
+      cx->lenbud = (uint32_t)len | (budget << 16);
+      cx->kq1 = (uint32_t)k | (q1 << 8);
+      cx->owner = threadIdx.x;
+      cx->pad = 0;
+    };
+
+    for (int k0 = 0; k0 < pp.W; k0 += 2) {
+      // ---- phase A: this read's two probes (headers of both buckets requested together)
+      bool part[2] = {false, false};
+      uint32_t bb[2] = {0, 0}, cc[2] = {0, 0};
+      uint4 hdr[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int k = k0 + j;
+        if (active && k < pp.W) part[j] = window_bucket(k, &bb[j]);
+        hdr[j] = make_uint4(0, 0, 0, 0);
+        if (part[j]) hdr[j] = *reinterpret_cast<const uint4*>(T + bb[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int k = k0 + j;
+        if (active && k < pp.W) wb[(uint64_t)i * pp.W + k] = part[j] ? bb[j] : WB_NONE;
+        if (part[j]) {
           valid |= 1u << k;
-          wb[(uint64_t)i * pp.W + k] = b;
-          ncand += c;
+          cc[j] = hdr[j].x;
+          ncand += cc[j];
+          if (cc[j]) window_ctx(k, bb[j], hdr[j].z, &s_ctx[2 * threadIdx.x + j]);
         }
-        if (c == 0) continue;
-        const uint64_t ovf = (uint64_t)hdr.z | ((uint64_t)hdr.w << 32);
-        // the read's own flanks and which of their bases exist
-        const int nl = q1 < 8 ? (int)q1 : 8;                                                // left of the window
-        const int nr = len - (int)q2 < 8 ? (len - (int)q2 < 0 ? 0 : len - (int)q2) : 8;     // right of it
-        const uint32_t rfl = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
-        const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) |
-                               ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
-        for (uint32_t e = 0; e < c; e++) {
-          const uint4* __restrict__ ep = e < BUCKET_INLINE ? &bk->e[e] : &E[ovf + (e - BUCKET_INLINE)];
-          const uint4 ent = *ep;
-          const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
-          int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
-          const int tcap = left + right;  // target length, saturated (exact below 65535)
-          if (lim0 > tcap) lim0 = tcap;
-          const bool fit0 = len <= lim0;
-          bool ok = (int)q1 <= left;                 // p = jx - q1 >= 0
-          if (left == 0) ok = ok && fit0;            // window at target position 0: pos-0 path
-          else ok = ok && (len - (int)q1 <= right);  // p + len <= T
-          const uint32_t x = rfl ^ ent.w;
-          const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
-          ok = ok && ((uint32_t)__popc(d) <= budget);
-          if (!ok) continue;
-          const uint32_t z = (left == (int)q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
-          const uint32_t pos_ok = left < 65535 ? 1u : 0u;
-          const uint4 dd = make_uint4(i, ent.y - q1,
-                                      (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - (int)q1) << 6), ent.x);
-          if (write) {
-            desc[out++] = dd;
+      }
+      uint32_t total = 0;
+      const uint32_t pre = wg_scan(cc[0] + cc[1], &total);
+      s_pref[2 * threadIdx.x] = pre;
+      s_pref[2 * threadIdx.x + 1] = pre + cc[0];
+      if (threadIdx.x == TILE - 1) s_pref[2 * TILE] = total;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint32_t p0 = pre + (j ? cc[0] : 0u);
+        for (uint32_t e = 0; e < cc[j] && p0 + e < SCR_OWN; e++) s_own[p0 + e] = (uint16_t)(2 * threadIdx.x + j);
+      }
+      __syncthreads();
+      // ---- phase B: the chunk's entries as one flat list
+      for (uint32_t t = threadIdx.x; t < total; t += TILE) {
+        uint32_t seg;
+        if (t < SCR_OWN) {
+          seg = s_own[t];
+        } else {  // rare: largest seg with s_pref[seg] <= t
+          uint32_t lo = 0, hi = 2 * TILE;
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (s_pref[mid] <= t) lo = mid; else hi = mid;
+          }
+          seg = lo;
+        }
+        const ScrCtx cx = s_ctx[seg];
+        const uint32_t e = t - s_pref[seg];
+        const uint4* __restrict__ ep = e < BUCKET_INLINE ? &T[cx.bucket].e[e] : &E[(uint64_t)cx.ovf + (e - BUCKET_INLINE)];
+        const uint4 ent = *ep;
+        uint4 dd;
+        const uint32_t owner = cx.owner;
+        if (!test_entry(ent, tile * TILE + owner, (int)(cx.kq1 & 0xFFu), (int)(cx.kq1 >> 8), (int)(cx.lenbud & 0xFFFFu),
+                        cx.lenbud >> 16, cx.rfl, cx.fmask, &dd))
+          continue;
+        const uint32_t ord = atomicAdd(&s_cnt[owner], 1u);
+        if (ord < EXP_STAGE) {
+          s_stage[owner * EXP_STAGE + ord] = dd;
+        } else {
+          const uint32_t slot = atomicAdd(&s_pooln, 1u);
+          if (slot < EXP_POOL && ord < 0xFFFFu) {
+            s_pool[slot] = dd;
+            s_ptag[slot] = (owner << 16) | ord;
           } else {
-            if (cnt < EXP_STAGE) {
-              s_stage[threadIdx.x * EXP_STAGE + cnt] = dd;
-            } else if (!rewalk) {
-              const uint32_t slot = atomicAdd(&s_pooln, 1u);
-              if (slot < EXP_POOL) {
-                s_pool[slot] = dd;
-                s_ptag[slot] = (threadIdx.x << 16) | (cnt & 0xFFFFu);
-              } else {
-                rewalk = true;
-              }
-            }
-            cnt++;
+            s_lost = 1;  // pool exhausted: the tile is redone one read per lane below
           }
         }
       }
-    };
-    if (active) walk(false, 0);
+      __syncthreads();  // s_ctx / s_pref / s_own are reused by the next chunk
+    }
     nvalid += __popc(valid);
 
-    // workgroup exclusive scan of cnt
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d);
-      if (lane >= d) inc += o;
-    }
-    __syncthreads();  // the previous tile's readers of s_wsum / s_base are done
-    if (lane == 63) s_wsum[wid] = inc;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < TILE / 64; w++) {
-      if (w < wid) woff += s_wsum[w];
-      total += s_wsum[w];
-    }
+    const uint32_t cnt = s_cnt[threadIdx.x];
+    uint32_t total = 0;
+    const uint32_t off = wg_scan(cnt, &total);
     const unsigned long long base = region0 + used;
     const bool fits = used + total <= region;  // else: the host grows desc and repeats the batch
     used += total;
-    const uint32_t mine = (uint32_t)base + woff + inc - cnt;
-    rewalk = rewalk || cnt > 0xFFFFu;  // ordinals in the pool tags are 16 bits
-    s_mine[threadIdx.x] = rewalk ? 0xFFFFFFFFu : mine;
+    const uint32_t mine = (uint32_t)base + off;
+    const bool lost = s_lost != 0;
+    s_mine[threadIdx.x] = mine;
     if (active) {
       cbase[i] = mine;
       vcnt[i] = fits ? cnt : 0u;
       rvalid[i] = valid;
-      if (fits) {
-        if (rewalk) {
-          walk(true, mine);
-        } else {
-          const uint32_t ns = cnt < EXP_STAGE ? cnt : EXP_STAGE;
-          for (uint32_t q = 0; q < ns; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
+      npair += cnt;
+      if (fits && !lost) {
+        const uint32_t ns = cnt < EXP_STAGE ? cnt : EXP_STAGE;
+        for (uint32_t q = 0; q < ns; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
+      }
+      if (fits && lost && cnt) {
+        // rare slow path: write this read's survivors by walking its buckets in this lane
+        uint64_t out = mine;
+        for (int k = 0; k < pp.W; k++) {
+          uint32_t b;
+          if (!window_bucket(k, &b)) continue;
+          const uint4 h = *reinterpret_cast<const uint4*>(T + b);
+          if (h.x == 0) continue;
+          ScrCtx cx;
+          window_ctx(k, b, h.z, &cx);
+          for (uint32_t e = 0; e < h.x; e++) {
+            const uint4* __restrict__ ep = e < BUCKET_INLINE ? &T[b].e[e] : &E[(uint64_t)cx.ovf + (e - BUCKET_INLINE)];
+            uint4 dd;
+            if (test_entry(*ep, i, k, pp.win[k], len, budget, cx.rfl, cx.fmask, &dd)) desc[out++] = dd;
+          }
         }
       }
-      npair += cnt;
     }
     __syncthreads();  // s_mine and the pool are complete
-    if (fits) {
+    if (fits && !lost) {
       const uint32_t pn = s_pooln < EXP_POOL ? s_pooln : EXP_POOL;
       for (uint32_t q = threadIdx.x; q < pn; q += TILE) {
         const uint32_t tag = s_ptag[q];
-        const uint32_t m = s_mine[tag >> 16];
-        if (m != 0xFFFFFFFFu) desc[m + (tag & 0xFFFFu)] = s_pool[q];
+        desc[s_mine[tag >> 16] + (tag & 0xFFFFu)] = s_pool[q];
       }
     }
     if (threadIdx.x == 0) {
       tbase[tile] = (uint32_t)base;
       tcount[tile] = fits ? total : 0u;
     }
+    __syncthreads();  // before the next tile resets s_cnt / s_pooln / s_lost
   }
   block_add_u64(nvalid, &counters[0]);
   block_add_u64(ncand, &counters[3]);
