@@ -478,7 +478,8 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
   return __popc(seen);
 }
 
-// per-pair result word: bits 0-15 mismatch count, bit 16 NX_DUP, bits 20-23 window
+// per-pair result word: bits 0-15 mismatch count, bit 16 NX_DUP, bits 20-23 window,
+// bits 24-31 the read's slot within its tile
 #define NX_REJECT 0xFFFFFFFFu
 #define NX_DUP 0x10000u  // accepted through this window, but an earlier window reports the tuple
 #define NX_MASK 0x1FFFFu
@@ -536,8 +537,6 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
                                                  const Bucket* __restrict__ T,
                                                  const uint4* __restrict__ E,
                                                  uint4* __restrict__ desc, uint64_t desc_cap,
-                                                 uint32_t* __restrict__ cbase,
-                                                 uint32_t* __restrict__ vcnt,
                                                  uint32_t* __restrict__ rvalid,
                                                  uint32_t* __restrict__ wb,
                                                  uint32_t* __restrict__ tbase,
@@ -547,22 +546,19 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
   // threads (a (read, window) with c entries owns c consecutive items): every entry load is
   // independent and they are issued together.  Walking each read's buckets in its own lane
   // instead costs a dependent L2 round trip per entry, repeated max-over-lanes times with most
-  // lanes idle -- that chain, not bandwidth, bounded the kernel.
+  // lanes idle -- that chain, not bandwidth, bounded the kernel.  Survivors are appended to the
+  // tile's range of `desc` in arrival order: k_confirm / k_select / k_emit take one workgroup
+  // per tile and never need a read's pairs to be adjacent.
   __shared__ uint32_t s_wsum[TILE / 64];
-  __shared__ ScrCtx s_ctx[2 * TILE];           // two windows per chunk
-  __shared__ uint32_t s_pref[2 * TILE + 1];    // exclusive prefix of the entry counts
-  __shared__ uint16_t s_own[SCR_OWN];          // flat item -> context
-  __shared__ uint32_t s_cnt[TILE];             // survivors per read so far
-  __shared__ uint4 s_stage[TILE * EXP_STAGE];  // first EXP_STAGE survivors of each read
-  __shared__ uint4 s_pool[EXP_POOL];           // the tile's survivors beyond that, any read
-  __shared__ uint32_t s_ptag[EXP_POOL];        // owner thread << 16 | ordinal within the read
-  __shared__ uint32_t s_mine[TILE];
-  __shared__ uint32_t s_pooln, s_lost;
+  __shared__ ScrCtx s_ctx[2 * TILE];         // two windows per chunk
+  __shared__ uint32_t s_pref[2 * TILE + 1];  // exclusive prefix of the entry counts
+  __shared__ uint16_t s_own[SCR_OWN];        // flat item -> context
+  __shared__ uint32_t s_tilecnt;             // survivors of the tile so far
   const int rw = RW ? RW : rw_rt;
   const bool has_m = rdm != nullptr;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  unsigned long long nvalid = 0, npair = 0, ncand = 0;
+  unsigned long long nvalid = 0, ncand = 0;
   const uint64_t region = desc_cap / gridDim.x;
   const uint64_t region0 = region * blockIdx.x;
   uint64_t used = 0;  // descriptors this workgroup has needed so far (uniform across the workgroup)
@@ -588,27 +584,6 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
     return woff + inc - v;
   };
 
-  // one index entry against one (read, window) context: fit rules + flank filter
-  auto test_entry = [&](const uint4& ent, uint32_t owner_i, int k, int q1, int len, uint32_t budget,
-                        uint32_t rfl, uint32_t fmask, uint4* dd) -> bool {
-    const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
-    int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
-    const int tcap = left + right;  // target length, saturated (exact below 65535)
-    if (lim0 > tcap) lim0 = tcap;
-    const bool fit0 = len <= lim0;
-    bool ok = q1 <= left;                 // p = jx - q1 >= 0
-    if (left == 0) ok = ok && fit0;       // window at target position 0: pos-0 path
-    else ok = ok && (len - q1 <= right);  // p + len <= T
-    const uint32_t x = rfl ^ ent.w;
-    const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
-    ok = ok && ((uint32_t)__popc(d) <= budget);
-    const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
-    const uint32_t pos_ok = left < 65535 ? 1u : 0u;
-    *dd = make_uint4(owner_i, ent.y - (uint32_t)q1,
-                     (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
-    return ok;
-  };
-
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t i = tile * TILE + threadIdx.x;
     const bool active = i < n;
@@ -620,29 +595,9 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
     const int len = (int)rec.len();
     const uint32_t budget = nmiss_tab[len];
     uint32_t valid = 0;
-    s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_pooln = 0; s_lost = 0; }
-
-    auto window_bucket = [&](int k, uint32_t* b) -> bool {
-      const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
-      bool part = (uint32_t)len >= q2;
-      if (part && pp.min_dinuc > 0) part = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
-      if (part) *b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
-      return part;
-    };
-    auto window_ctx = [&](int k, uint32_t b, uint32_t ovf, ScrCtx* cx) {
-      const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
-      const int nl = q1 < 8 ? (int)q1 : 8;                                             // left of the window
-      const int nr = len - (int)q2 < 8 ? (len - (int)q2 < 0 ? 0 : len - (int)q2) : 8;  // right of it
-      cx->bucket = b;
-      cx->ovf = ovf;
-      cx->rfl = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
-      cx->fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) | ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
-      cx->lenbud = (uint32_t)len | (budget << 16);
-      cx->kq1 = (uint32_t)k | (q1 << 8);
-      cx->owner = threadIdx.x;
-      cx->pad = 0;
-    };
+    if (threadIdx.x == 0) s_tilecnt = 0;
+    const uint64_t base = region0 + used;
+    const uint64_t room = region > used ? region - used : 0;  // descriptors this tile may still write
 
     for (int k0 = 0; k0 < pp.W; k0 += 2) {
       // ---- phase A: this read's two probes (headers of both buckets requested together)
@@ -652,7 +607,14 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int k = k0 + j;
-        if (active && k < pp.W) part[j] = window_bucket(k, &bb[j]);
+        if (active && k < pp.W) {
+          // does window k of this read take part (cmd/muscato_window_reads/main.go:106-118)
+          const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
+          bool pt = (uint32_t)len >= q2;
+          if (pt && pp.min_dinuc > 0) pt = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
+          if (pt) bb[j] = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+          part[j] = pt;
+        }
         hdr[j] = make_uint4(0, 0, 0, 0);
         if (part[j]) hdr[j] = *reinterpret_cast<const uint4*>(T + bb[j]);
       }
@@ -664,7 +626,21 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
           valid |= 1u << k;
           cc[j] = hdr[j].x;
           ncand += cc[j];
-          if (cc[j]) window_ctx(k, bb[j], hdr[j].z, &s_ctx[2 * threadIdx.x + j]);
+          if (cc[j]) {
+            const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
+            const int nl = q1 < 8 ? (int)q1 : 8;                                             // left of the window
+            const int nr = len - (int)q2 < 8 ? (len - (int)q2 < 0 ? 0 : len - (int)q2) : 8;  // right of it
+            ScrCtx cx;
+            cx.bucket = bb[j];
+            cx.ovf = hdr[j].z;
+            cx.rfl = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+            cx.fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) | ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
+            cx.lenbud = (uint32_t)len | (budget << 16);
+            cx.kq1 = (uint32_t)k | (q1 << 8);
+            cx.owner = threadIdx.x;
+            cx.pad = 0;
+            s_ctx[2 * threadIdx.x + j] = cx;
+          }
         }
       }
       uint32_t total = 0;
@@ -695,82 +671,46 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
         const uint32_t e = t - s_pref[seg];
         const uint4* __restrict__ ep = e < BUCKET_INLINE ? &T[cx.bucket].e[e] : &E[(uint64_t)cx.ovf + (e - BUCKET_INLINE)];
         const uint4 ent = *ep;
-        uint4 dd;
-        const uint32_t owner = cx.owner;
-        if (!test_entry(ent, tile * TILE + owner, (int)(cx.kq1 & 0xFFu), (int)(cx.kq1 >> 8), (int)(cx.lenbud & 0xFFFFu),
-                        cx.lenbud >> 16, cx.rfl, cx.fmask, &dd))
-          continue;
-        const uint32_t ord = atomicAdd(&s_cnt[owner], 1u);
-        if (ord < EXP_STAGE) {
-          s_stage[owner * EXP_STAGE + ord] = dd;
-        } else {
-          const uint32_t slot = atomicAdd(&s_pooln, 1u);
-          if (slot < EXP_POOL && ord < 0xFFFFu) {
-            s_pool[slot] = dd;
-            s_ptag[slot] = (owner << 16) | ord;
-          } else {
-            s_lost = 1;  // pool exhausted: the tile is redone one read per lane below
-          }
-        }
+        // fit rules + flank filter from the entry alone
+        const int k = (int)(cx.kq1 & 0xFFu), q1 = (int)(cx.kq1 >> 8), rlen = (int)(cx.lenbud & 0xFFFFu);
+        const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
+        int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
+        const int tcap = left + right;  // target length, saturated (exact below 65535)
+        if (lim0 > tcap) lim0 = tcap;
+        const bool fit0 = rlen <= lim0;
+        bool ok = q1 <= left;                  // p = jx - q1 >= 0
+        if (left == 0) ok = ok && fit0;        // window at target position 0: pos-0 path
+        else ok = ok && (rlen - q1 <= right);  // p + len <= T
+        const uint32_t x = cx.rfl ^ ent.w;
+        const uint32_t d = (x | (x >> 1)) & 0x55555555u & cx.fmask;
+        ok = ok && ((uint32_t)__popc(d) <= (cx.lenbud >> 16));
+        if (!ok) continue;
+        const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
+        const uint32_t pos_ok = left < 65535 ? 1u : 0u;
+        const uint32_t slot = atomicAdd(&s_tilecnt, 1u);
+        if (slot < room)
+          desc[base + slot] = make_uint4(tile * TILE + cx.owner, ent.y - (uint32_t)q1,
+                                         (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
       }
       __syncthreads();  // s_ctx / s_pref / s_own are reused by the next chunk
     }
     nvalid += __popc(valid);
-
-    const uint32_t cnt = s_cnt[threadIdx.x];
-    uint32_t total = 0;
-    const uint32_t off = wg_scan(cnt, &total);
-    const unsigned long long base = region0 + used;
-    const bool fits = used + total <= region;  // else: the host grows desc and repeats the batch
+    if (active) rvalid[i] = valid;
+    const uint32_t total = s_tilecnt;
+    const bool fits = total <= room;  // else: the host grows desc and repeats the batch
     used += total;
-    const uint32_t mine = (uint32_t)base + off;
-    const bool lost = s_lost != 0;
-    s_mine[threadIdx.x] = mine;
-    if (active) {
-      cbase[i] = mine;
-      vcnt[i] = fits ? cnt : 0u;
-      rvalid[i] = valid;
-      npair += cnt;
-      if (fits && !lost) {
-        const uint32_t ns = cnt < EXP_STAGE ? cnt : EXP_STAGE;
-        for (uint32_t q = 0; q < ns; q++) desc[mine + q] = s_stage[threadIdx.x * EXP_STAGE + q];
-      }
-      if (fits && lost && cnt) {
-        // rare slow path: write this read's survivors by walking its buckets in this lane
-        uint64_t out = mine;
-        for (int k = 0; k < pp.W; k++) {
-          uint32_t b;
-          if (!window_bucket(k, &b)) continue;
-          const uint4 h = *reinterpret_cast<const uint4*>(T + b);
-          if (h.x == 0) continue;
-          ScrCtx cx;
-          window_ctx(k, b, h.z, &cx);
-          for (uint32_t e = 0; e < h.x; e++) {
-            const uint4* __restrict__ ep = e < BUCKET_INLINE ? &T[b].e[e] : &E[(uint64_t)cx.ovf + (e - BUCKET_INLINE)];
-            uint4 dd;
-            if (test_entry(*ep, i, k, pp.win[k], len, budget, cx.rfl, cx.fmask, &dd)) desc[out++] = dd;
-          }
-        }
-      }
-    }
-    __syncthreads();  // s_mine and the pool are complete
-    if (fits && !lost) {
-      const uint32_t pn = s_pooln < EXP_POOL ? s_pooln : EXP_POOL;
-      for (uint32_t q = threadIdx.x; q < pn; q += TILE) {
-        const uint32_t tag = s_ptag[q];
-        desc[s_mine[tag >> 16] + (tag & 0xFFFFu)] = s_pool[q];
-      }
-    }
     if (threadIdx.x == 0) {
       tbase[tile] = (uint32_t)base;
       tcount[tile] = fits ? total : 0u;
     }
-    __syncthreads();  // before the next tile resets s_cnt / s_pooln / s_lost
+    __syncthreads();  // before the next tile resets s_tilecnt
   }
   block_add_u64(nvalid, &counters[0]);
   block_add_u64(ncand, &counters[3]);
-  block_add_u64(npair, &counters[4]);
-  if (threadIdx.x == 0) atomicMax(&counters[7], (unsigned long long)used);
+  if (threadIdx.x == 0) {
+    atomicAdd(&counters[4], (unsigned long long)used);
+    atomicMax(&counters[7], (unsigned long long)used);
+  }
 }
 
 // u32 mask of the bits of window [q1, q1+ww) (2 bits per base) that fall in record word j
@@ -881,101 +821,90 @@ __global__ __launch_bounds__(256) void k_confirm(
   // window-key block's MaxMatches); it is reported here only if k is the first such window.
   const bool own = ((exact >> k) & 1u) && (nx <= nmiss_tab[len]);
   const uint32_t kmin = (uint32_t)(__ffs(exact) - 1);
-  const uint32_t code = !own ? NX_REJECT : ((kmin == k ? nx : (nx | NX_DUP)) | (k << 20));
+  const uint32_t code = !own ? NX_REJECT : ((kmin == k ? nx : (nx | NX_DUP)) | (k << 20) | ((ri & (TILE - 1)) << 24));
   __builtin_nontemporal_store(code, &p_nx[idx]);
   }
 }
 
-// Per-read selection, two passes around a scan (no per-hit atomics, deterministic order).
-// Pass 1, one thread per read: best mismatch count over its accepted pairs and the number of
-// tuples with nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60), or all
-// accepted tuples when apply_mmtol == 0.
+// (sketch size)
 #define BLOCK_LDS_BITS 11
 
+// k_select -- per-read best + MMTol (cmd/muscato_combine_windows/main.go:36-60) and the
+// MaxMatches block accounting, one workgroup per tile (persistent over tiles).  A tile's pairs
+// lie in one range of p_nx in any order; per-read state lives in LDS.
+//   pass 1: best[read] = min nmiss over its reported pairs; wcnt[read][window] = pairs that
+//           window's confirm accepts (its share of the (window,key) block, which
+//           cmd/muscato_confirm/main.go:233-242, 424-448 truncate at MaxMatches)
+//   pass 2: hcnt[read] = pairs with nmiss <= best + MMTol (all accepted pairs when
+//           apply_mmtol == 0), hthr[read] = that threshold
 // block_mode 0: no MaxMatches accounting.
-// block_mode 1: screening -- each workgroup keeps a count-min sketch of (window, key) -> pairs
-//   accepted through that window in LDS; if no sketch cell of any workgroup of any launch
-//   reaches `block_thr` = floor(MaxMatches / number of workgroup-launches), then by pigeonhole no
-//   block can hold more than MaxMatches pairs (cells only over-estimate).  Otherwise
-//   counters[6] is raised and the host repeats the pass in mode 2.
-// block_mode 2: exact -- one global atomic per (read, window) into a 2^22-cell table
-//   (70 M memory-side atomics per cfg3 pass, ~1.9 ms: only when mode 1 is inconclusive).
-__global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
-                                                    const uint32_t* __restrict__ cbase,
-                                                    const uint32_t* __restrict__ vcnt,
-                                                    const uint32_t* __restrict__ p_nx,
-                                                    const uint32_t* __restrict__ wb, int block_mode,
-                                                    uint32_t block_thr,
-                                                    uint32_t* __restrict__ block_table,
-                                                    uint32_t* __restrict__ hcnt,
-                                                    uint32_t* __restrict__ hthr,
-                                                    unsigned long long* __restrict__ counters) {
+// block_mode 1: screening -- each workgroup keeps a count-min sketch of (window, key) -> accepted
+//   pairs in LDS across all its tiles; if no sketch cell of any workgroup of any launch reaches
+//   `block_thr` = floor(MaxMatches / number of workgroup-launches), then by pigeonhole no block can
+//   hold more than MaxMatches pairs (cells only over-estimate).  Otherwise counters[6] is raised
+//   and the host repeats the pass in mode 2.
+// block_mode 2: exact -- one global atomic per (read, window) into a 2^22-cell table.
+__global__ __launch_bounds__(TILE) void k_select(uint32_t n, PathParams pp,
+                                                 const uint32_t* __restrict__ tbase,
+                                                 const uint32_t* __restrict__ tcount,
+                                                 const uint32_t* __restrict__ p_nx,
+                                                 const uint32_t* __restrict__ wb, int block_mode,
+                                                 uint32_t block_thr, uint32_t* __restrict__ block_table,
+                                                 uint32_t* __restrict__ hcnt, uint32_t* __restrict__ hthr,
+                                                 unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t s_best[TILE], s_cnt[TILE];
+  __shared__ uint32_t s_wcnt[TILE * MUSC_MAX_WINDOWS];
   __shared__ uint32_t s_sketch[1 << BLOCK_LDS_BITS];
+  const uint32_t ntiles = (n + TILE - 1) / TILE;
   if (block_mode == 1) {
     for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += blockDim.x) s_sketch[t] = 0;
-    __syncthreads();
   }
   unsigned long long acc = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t b = cbase[i], e = b + vcnt[i];
-    uint32_t best = 0xFFFFFFFFu, na = 0, nbest = 0;
-    // a read's pairs are stored window-major: count the pairs each window's confirm accepts
-    // and add them to that (window, key) block (cmd/muscato_confirm/main.go:233-242, 424-448
-    // truncate a block at MaxMatches).  The index bucket identifies the key.
-    // per-window accepted counts, 8 bits each (windows 0-7 in wc0, 8-15 in wc1); a count
-    // that would pass 255 raises the "hot" flag instead (=> exact pass)
-    uint64_t wc0 = 0, wc1 = 0;
-    bool sat = false;
-    for (uint32_t j = b; j < e; j++) {
-      const uint32_t w = p_nx[j];
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile is done with the LDS state
+    s_best[threadIdx.x] = 0xFFFFFFFFu;
+    s_cnt[threadIdx.x] = 0;
+    if (block_mode)
+      for (uint32_t t = threadIdx.x; t < TILE * (uint32_t)pp.W; t += TILE) s_wcnt[t] = 0;
+    __syncthreads();
+    const uint32_t tn = tcount[tile];
+    const uint64_t tb = tbase[tile];
+    for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
+      const uint32_t w = p_nx[tb + tj];
       if (w == NX_REJECT) continue;
-      const uint32_t v = w & NX_MASK;
-      if (block_mode) {
-        const uint32_t k = w >> 20;
-        uint64_t& wc = k < 8 ? wc0 : wc1;
-        const uint32_t sh = (k & 7u) * 8u;
-        if (((wc >> sh) & 0xFFull) == 0xFFull) sat = true; else wc += 1ull << sh;
-      }
-      if (v & NX_DUP) continue;
-      nbest = v < best ? 1u : (v == best ? nbest + 1u : nbest);
-      best = v < best ? v : best;
-      na++;
+      const uint32_t rl = w >> 24;
+      if (block_mode) atomicAdd(&s_wcnt[rl * pp.W + ((w >> 20) & 15u)], 1u);
+      if (w & NX_DUP) continue;
+      atomicMin(&s_best[rl], w & 0xFFFFu);
+      acc++;
     }
-    if (block_mode == 2 && sat) {
-      // a read with more than 255 accepted pairs in one window: count pair by pair (rare)
-      for (uint32_t j = b; j < e; j++) {
-        const uint32_t w = p_nx[j];
-        if (w == NX_REJECT) continue;
-        const uint32_t k = w >> 20;
-        const uint64_t h = mix64(((uint64_t)k << 32) | wb[(uint64_t)i * pp.W + k]);
-        atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], 1u);
-      }
-    } else if (block_mode) {
-      for (int k = 0; k < pp.W; k++) {  // uniform loop: the atomics of a wave issue together
-        const uint32_t cw = (uint32_t)(((k < 8 ? wc0 : wc1) >> ((k & 7) * 8)) & 0xFFull);
-        if (cw) {
-          const uint64_t h = mix64(((uint64_t)k << 32) | wb[(uint64_t)i * pp.W + k]);
-          if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - BLOCK_LDS_BITS)], cw);
-          else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
-        }
-      }
-      if (sat) atomicOr(&counters[6], 1ull);  // screening cannot bound this read: exact pass
+    __syncthreads();
+    for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
+      const uint32_t w = p_nx[tb + tj];
+      if (w == NX_REJECT || (w & NX_DUP)) continue;
+      const uint32_t rl = w >> 24;
+      const uint32_t thr = pp.apply_mmtol ? s_best[rl] + (uint32_t)pp.mmtol : 0xFFFFu;
+      if ((w & 0xFFFFu) <= thr) atomicAdd(&s_cnt[rl], 1u);
     }
-    uint32_t cnt = 0, thr = 0;
-    if (best != 0xFFFFFFFFu) {
-      thr = pp.apply_mmtol ? best + (uint32_t)pp.mmtol : 0xFFFFu;
+    if (block_mode) {
+      for (uint32_t t = threadIdx.x; t < TILE * (uint32_t)pp.W; t += TILE) {
+        const uint32_t cw = s_wcnt[t];
+        if (!cw) continue;
+        const uint32_t rl = t / pp.W, k = t % pp.W;
+        const uint64_t h = mix64(((uint64_t)k << 32) | wb[((uint64_t)tile * TILE + rl) * pp.W + k]);
+        if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - BLOCK_LDS_BITS)], cw);
+        else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
+      }
+    }
+    __syncthreads();
+    const uint32_t i = tile * TILE + threadIdx.x;
+    if (i < n) {
+      const uint32_t c = s_cnt[threadIdx.x];
+      uint32_t thr = pp.apply_mmtol ? s_best[threadIdx.x] + (uint32_t)pp.mmtol : 0xFFFFu;
       if (thr > 0xFFFFu) thr = 0xFFFFu;
-      if (!pp.apply_mmtol) {
-        cnt = na;
-      } else if (pp.mmtol == 0) {
-        cnt = nbest;  // tuples at the best count, found in the same pass
-      } else {
-        for (uint32_t j = b; j < e; j++) cnt += (p_nx[j] & NX_MASK) <= thr;  // REJECT/DUP are > thr
-      }
+      hcnt[i] = c;
+      hthr[i] = c ? thr : 0xFFFFFFFFu;
     }
-    hcnt[i] = cnt;
-    hthr[i] = cnt ? thr : 0xFFFFFFFFu;
-    acc += na;
   }
   block_add_u64(acc, &counters[1]);
   if (blockIdx.x == 0 && threadIdx.x == 0) hcnt[n] = 0;
@@ -987,6 +916,52 @@ __global__ __launch_bounds__(256) void k_best_count(uint32_t n, PathParams pp,
   }
 }
 
+// k_emit -- one workgroup per tile: write the tuples of each read at
+// hits[counters[2] + hbase[read] ...] (hbase = scan of hcnt).  A read's tuples are contiguous
+// and reads are in order; the order of the tuples within one read is arrival order.
+__global__ __launch_bounds__(TILE) void k_emit(uint64_t r0, uint32_t n, const uint32_t* __restrict__ tbase,
+                                               const uint32_t* __restrict__ tcount,
+                                               const uint32_t* __restrict__ hbase,
+                                               const uint32_t* __restrict__ hthr,
+                                               const uint4* __restrict__ cdesc,
+                                               const uint32_t* __restrict__ p_nx,
+                                               const uint64_t* __restrict__ seq_off,
+                                               musc_hit* __restrict__ hits,
+                                               const unsigned long long* __restrict__ counters) {
+  __shared__ uint32_t s_ord[TILE], s_thr[TILE], s_base[TILE];
+  const unsigned long long base = counters[2];
+  const uint32_t ntiles = (n + TILE - 1) / TILE;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    const uint32_t i = tile * TILE + threadIdx.x;
+    s_ord[threadIdx.x] = 0;
+    s_thr[threadIdx.x] = i < n ? hthr[i] : 0xFFFFFFFFu;
+    s_base[threadIdx.x] = i < n ? hbase[i] : 0u;
+    __syncthreads();
+    const uint32_t tn = tcount[tile];
+    const uint64_t tb = tbase[tile];
+    for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
+      const uint32_t w = p_nx[tb + tj];
+      if (w == NX_REJECT || (w & NX_DUP)) continue;
+      const uint32_t rl = w >> 24, v = w & 0xFFFFu;
+      const uint32_t thr = s_thr[rl];
+      if (thr == 0xFFFFFFFFu || v > thr) continue;
+      const uint32_t ord = atomicAdd(&s_ord[rl], 1u);
+      const uint4 ds = cdesc[tb + tj];
+      // position in the target: carried in the descriptor unless the target is so long that
+      // the entry's 16-bit distance saturated (then one gather of the gene's offset)
+      const uint32_t pos = ((ds.z >> 5) & 1u) ? ((ds.z >> 6) & 0xFFFFu) : (uint32_t)((uint64_t)ds.y - seq_off[ds.w]);
+      *reinterpret_cast<uint4*>(&hits[base + s_base[rl] + ord]) =
+          make_uint4((uint32_t)(r0 + tile * TILE + rl), ds.w, pos, v);
+    }
+  }
+}
+
+// counters[2] (hits so far) += hbase[n] (hits of this batch)
+__global__ void k_advance(const uint32_t* __restrict__ hbase, uint32_t n, unsigned long long* counters) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) counters[2] += hbase[n];
+}
+
 // number of block counters above MaxMatches (hash collisions only inflate counters, so 0 is
 // a proof that no window-key block overflowed)
 __global__ void k_block_overflow(const uint32_t* __restrict__ block_table, uint32_t max_matches,
@@ -995,43 +970,6 @@ __global__ void k_block_overflow(const uint32_t* __restrict__ block_table, uint3
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << BLOCK_TABLE_BITS); i += gridDim.x * blockDim.x)
     c += block_table[i] > max_matches;
   block_add_u64(c, &counters[5]);
-}
-
-// Pass 2, one thread per read: write its tuples at hits[counters[2] + hbase[i] ...].
-__global__ __launch_bounds__(256) void k_emit(uint64_t r0, uint32_t n, const uint32_t* __restrict__ cbase,
-                                              const uint32_t* __restrict__ vcnt,
-                                              const uint32_t* __restrict__ hbase,
-                                              const uint32_t* __restrict__ hthr,
-                                              const uint4* __restrict__ cdesc,
-                                              const uint32_t* __restrict__ p_nx,
-                                              const uint64_t* __restrict__ seq_off,
-                                              musc_hit* __restrict__ hits,
-                                              const unsigned long long* __restrict__ counters) {
-  const unsigned long long base = counters[2];
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t thr = hthr[i];
-    if (thr == 0xFFFFFFFFu) continue;
-    unsigned long long slot = base + hbase[i];
-    const uint32_t b = cbase[i], e = b + vcnt[i];
-    for (uint32_t j = b; j < e; j++) {
-      const uint32_t v = p_nx[j] & NX_MASK;
-      if (v > thr) continue;  // NX_REJECT and NX_DUP codes are > thr always
-      const uint4 ds = cdesc[j];
-      musc_hit h;
-      h.read_idx = (uint32_t)(r0 + i);
-      h.gene_idx = ds.w;
-      // position in the target: carried in the descriptor unless the target is so long that
-      // the entry's 16-bit distance saturated (then one gather of the gene's offset)
-      h.pos = ((ds.z >> 5) & 1u) ? (ds.z >> 6) : (uint32_t)((uint64_t)ds.y - seq_off[ds.w]);
-      h.nmiss = v;
-      *reinterpret_cast<uint4*>(&hits[slot++]) = make_uint4(h.read_idx, h.gene_idx, h.pos, h.nmiss);
-    }
-  }
-}
-
-// counters[2] (hits so far) += hbase[n] (hits of this batch)
-__global__ void k_advance(const uint32_t* __restrict__ hbase, uint32_t n, unsigned long long* counters) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) counters[2] += hbase[n];
 }
 
 __global__ void k_rebase_hits(musc_hit* h, uint64_t n, uint32_t add) {
@@ -1088,7 +1026,7 @@ struct musc_ctx {
   uint32_t max_len = 0;
 
   // per-batch work buffers
-  DevBuf<uint32_t> wb, vcnt, cbase, rvalid, tbase, tcount, scan_tmp, hcnt, hbase, hthr;
+  DevBuf<uint32_t> wb, rvalid, tbase, tcount, scan_tmp, hcnt, hbase, hthr;
   DevBuf<uint4> cdesc;
   DevBuf<uint32_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
@@ -1256,8 +1194,8 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
   const dim3 block(TILE);
   if (stage == 0) {
     hipLaunchKernelGGL((k_screen<RW>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd, c->rdm, r0,
-                       n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap, c->cbase.p,
-                       c->vcnt.p, c->rvalid.p, c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
+                       n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap, c->rvalid.p,
+                       c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
   } else {
     const dim3 grid(nblk(n, TILE));  // one workgroup per k_screen tile
     if (mask)
@@ -1325,7 +1263,7 @@ void musc_destroy(musc_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   free_db(c);
   free_reads(c);
-  c->wb.release(); c->tbase.release(); c->vcnt.release(); c->cbase.release();
+  c->wb.release(); c->tbase.release();
   c->scan_tmp.release(); c->hcnt.release(); c->hbase.release(); c->hthr.release();
   c->rvalid.release(); c->tcount.release(); c->cdesc.release(); c->p_nx.release();
   c->nmiss_tab.release();
@@ -1697,8 +1635,6 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     const int W = pp.W;
     const uint32_t ntiles = nblk(n, TILE);
     if ((rc = ensure(c, c->wb, (uint64_t)n * W))) return rc;
-    if ((rc = ensure(c, c->vcnt, (uint64_t)n + 1))) return rc;
-    if ((rc = ensure(c, c->cbase, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->rvalid, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->tbase, (uint64_t)ntiles + 1))) return rc;
     if ((rc = ensure(c, c->tcount, (uint64_t)ntiles + 1))) return rc;
@@ -1739,7 +1675,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
 
     if (total) {
-      const dim3 sg(std::min(nblk(n, 256), MAX_GRID));
+      const dim3 sg(std::min(nblk(n, TILE), MAX_GRID));
 
       tm.begin(3);
       launch_stage(c, 2, mask, r0, n, pp);
@@ -1748,15 +1684,15 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       c->stats.confirm_launches++;
 
       tm.begin(4);
-      hipLaunchKernelGGL(k_best_count, sg, dim3(256), 0, c->stream, n, pp, c->cbase.p, c->vcnt.p, c->p_nx.p,
-                         c->wb.p, block_mode, block_thr, c->block_table.p, c->hcnt.p, c->hthr.p, c->counters);
+      hipLaunchKernelGGL(k_select, sg, dim3(TILE), 0, c->stream, n, pp, c->tbase.p, c->tcount.p, c->p_nx.p, c->wb.p,
+                         block_mode, block_thr, c->block_table.p, c->hcnt.p, c->hthr.p, c->counters);
       HIPCHK(c, hipGetLastError());
       tm.begin(1);
       rc = scan_u32(c, c->hcnt.p, c->hbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
       if (rc) return rc;
       tm.end(1);
-      hipLaunchKernelGGL(k_emit, sg, dim3(256), 0, c->stream, r0, n, c->cbase.p, c->vcnt.p, c->hbase.p, c->hthr.p, c->cdesc.p,
-                         c->p_nx.p, c->seq_off, c->hits.p, c->counters);
+      hipLaunchKernelGGL(k_emit, sg, dim3(TILE), 0, c->stream, r0, n, c->tbase.p, c->tcount.p, c->hbase.p, c->hthr.p,
+                         c->cdesc.p, c->p_nx.p, c->seq_off, c->hits.p, c->counters);
       HIPCHK(c, hipGetLastError());
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->hbase.p, n, c->counters);
       HIPCHK(c, hipGetLastError());
