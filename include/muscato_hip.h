@@ -90,9 +90,9 @@ typedef struct {
   uint64_t confirm_bytes;   /* algorithmic bytes of the confirm launches (63 B/pair at 100 bp) */
   uint32_t confirm_launches;
   uint32_t n_batches;
-  float ms_seed;            /* HIP-event time of each kernel family, summed over batches */
-  float ms_scan;
-  float ms_expand;
+  float ms_screen;          /* HIP-event time of each kernel family, summed over batches:  */
+  float ms_scan;            /*   k_screen | scans | (unused) | k_confirm | k_select+k_emit  */
+  float ms_unused0;
   float ms_confirm;
   float ms_select;
   float ms_total;           /* first launch to last completion on the context's stream  */

@@ -40,7 +40,7 @@ class MuscStats(ctypes.Structure):
         ("n_hits", ctypes.c_uint64), ("n_overflow_blocks", ctypes.c_uint64),
         ("confirm_bytes", ctypes.c_uint64),
         ("confirm_launches", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),
-        ("ms_seed", ctypes.c_float), ("ms_scan", ctypes.c_float), ("ms_expand", ctypes.c_float),
+        ("ms_screen", ctypes.c_float), ("ms_scan", ctypes.c_float), ("ms_unused0", ctypes.c_float),
         ("ms_confirm", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_total", ctypes.c_float),
         ("ms_index_build", ctypes.c_float), ("ms_reserved", ctypes.c_float),
     ]

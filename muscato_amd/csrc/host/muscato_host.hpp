@@ -773,10 +773,10 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
       musc_stats s;
       musc_get_stats(ctxs[g], &s);
       log.printf("gpu %d: reads %llu windows %llu candidates %llu pairs %llu accepted %llu hits %llu; device %.3f ms "
-                 "(seed %.3f scan %.3f expand %.3f confirm %.3f select %.3f), index build %.1f ms, confirm %.1f GB/s",
+                 "(screen %.3f scan %.3f confirm %.3f select %.3f), index build %.1f ms, confirm %.1f GB/s",
                  cfg.Device + g, (unsigned long long)s.n_reads, (unsigned long long)s.n_read_windows,
                  (unsigned long long)s.n_candidates, (unsigned long long)s.n_pairs, (unsigned long long)s.n_accepted,
-                 (unsigned long long)s.n_hits, s.ms_total, s.ms_seed, s.ms_scan, s.ms_expand, s.ms_confirm, s.ms_select,
+                 (unsigned long long)s.n_hits, s.ms_total, s.ms_screen, s.ms_scan, s.ms_confirm, s.ms_select,
                  s.ms_index_build, s.ms_confirm > 0 ? s.confirm_bytes / 1e6 / s.ms_confirm : 0.0);
     }
   }

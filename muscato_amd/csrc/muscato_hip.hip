@@ -550,9 +550,11 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
   // tile's range of `desc` in arrival order: k_confirm / k_select / k_emit take one workgroup
   // per tile and never need a read's pairs to be adjacent.
   __shared__ uint32_t s_wsum[TILE / 64];
-  __shared__ ScrCtx s_ctx[2 * TILE];         // two windows per chunk
+  __shared__ uint4 s_bkt[2 * TILE][4];       // the 64-byte buckets probed by this chunk (2 windows per read)
+  __shared__ uint32_t s_rfl[2 * TILE];       // per probe: the read's own 8+8 flanking bases
+  __shared__ uint32_t s_lenbud[2 * TILE];    // read length | mismatch budget << 16
   __shared__ uint32_t s_pref[2 * TILE + 1];  // exclusive prefix of the entry counts
-  __shared__ uint16_t s_own[SCR_OWN];        // flat item -> context
+  __shared__ uint16_t s_own[SCR_OWN];        // flat item -> probe
   __shared__ uint32_t s_tilecnt;             // survivors of the tile so far
   const int rw = RW ? RW : rw_rt;
   const bool has_m = rdm != nullptr;
@@ -600,48 +602,50 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
     const uint64_t room = region > used ? region - used : 0;  // descriptors this tile may still write
 
     for (int k0 = 0; k0 < pp.W; k0 += 2) {
-      // ---- phase A: this read's two probes (headers of both buckets requested together)
+      // ---- phase A: which of this read's next two windows take part, and their buckets
       bool part[2] = {false, false};
-      uint32_t bb[2] = {0, 0}, cc[2] = {0, 0};
-      uint4 hdr[2];
+      uint32_t bb[2] = {0, 0};
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int k = k0 + j;
         if (active && k < pp.W) {
-          // does window k of this read take part (cmd/muscato_window_reads/main.go:106-118)
+          // cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185
           const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
           bool pt = (uint32_t)len >= q2;
           if (pt && pp.min_dinuc > 0) pt = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
-          if (pt) bb[j] = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+          if (pt) {
+            bb[j] = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+            s_rfl[2 * threadIdx.x + j] = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+            s_lenbud[2 * threadIdx.x + j] = (uint32_t)len | (budget << 16);
+            valid |= 1u << k;
+          }
           part[j] = pt;
+          wb[(uint64_t)i * pp.W + k] = pt ? bb[j] : WB_NONE;
         }
-        hdr[j] = make_uint4(0, 0, 0, 0);
-        if (part[j]) hdr[j] = *reinterpret_cast<const uint4*>(T + bb[j]);
       }
+      // The buckets themselves: four lanes fetch one 64-byte bucket, 16 bytes each, so one
+      // wave instruction brings 16 whole buckets (16 lines touched instead of 64) and every
+      // line is fetched once -- count and inline entries arrive together and wait in LDS for
+      // the flat phase (the XCD's L2 turns over in microseconds here; re-reading the entries
+      // later from global memory fetched half of the lines from HBM twice).
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        const int k = k0 + j;
-        if (active && k < pp.W) wb[(uint64_t)i * pp.W + k] = part[j] ? bb[j] : WB_NONE;
-        if (part[j]) {
-          valid |= 1u << k;
-          cc[j] = hdr[j].x;
-          ncand += cc[j];
-          if (cc[j]) {
-            const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
-            const int nl = q1 < 8 ? (int)q1 : 8;                                             // left of the window
-            const int nr = len - (int)q2 < 8 ? (len - (int)q2 < 0 ? 0 : len - (int)q2) : 8;  // right of it
-            ScrCtx cx;
-            cx.bucket = bb[j];
-            cx.ovf = hdr[j].z;
-            cx.rfl = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
-            cx.fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) | ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
-            cx.lenbud = (uint32_t)len | (budget << 16);
-            cx.kq1 = (uint32_t)k | (q1 << 8);
-            cx.owner = threadIdx.x;
-            cx.pad = 0;
-            s_ctx[2 * threadIdx.x + j] = cx;
-          }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int src = rr * 16 + (lane >> 2);  // the lane of this wave whose probe we fetch
+          const uint32_t b = __shfl(bb[j], src);
+          const int pt = __shfl((int)part[j], src);
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (pt) v = reinterpret_cast<const uint4*>(T + b)[lane & 3];
+          s_bkt[2 * (wid * 64 + src) + j][lane & 3] = v;
         }
+      }
+      __syncthreads();
+      uint32_t cc[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        cc[j] = s_bkt[2 * threadIdx.x + j][0].x;  // 0 for probes that take no part
+        ncand += cc[j];
       }
       uint32_t total = 0;
       const uint32_t pre = wg_scan(cc[0] + cc[1], &total);
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
         for (uint32_t e = 0; e < cc[j] && p0 + e < SCR_OWN; e++) s_own[p0 + e] = (uint16_t)(2 * threadIdx.x + j);
       }
       __syncthreads();
-      // ---- phase B: the chunk's entries as one flat list
+      // ---- phase B: the chunk's entries as one flat list, in (read, window, entry) order
       for (uint32_t t = threadIdx.x; t < total; t += TILE) {
         uint32_t seg;
         if (t < SCR_OWN) {
@@ -667,12 +671,17 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
           }
           seg = lo;
         }
-        const ScrCtx cx = s_ctx[seg];
         const uint32_t e = t - s_pref[seg];
-        const uint4* __restrict__ ep = e < BUCKET_INLINE ? &T[cx.bucket].e[e] : &E[(uint64_t)cx.ovf + (e - BUCKET_INLINE)];
-        const uint4 ent = *ep;
+        const uint4 hd = s_bkt[seg][0];
+        const uint4 ent = e < BUCKET_INLINE ? s_bkt[seg][1 + e]
+                                            : E[((uint64_t)hd.z | ((uint64_t)hd.w << 32)) + (e - BUCKET_INLINE)];
         // fit rules + flank filter from the entry alone
-        const int k = (int)(cx.kq1 & 0xFFu), q1 = (int)(cx.kq1 >> 8), rlen = (int)(cx.lenbud & 0xFFFFu);
+        const int k = k0 + (int)(seg & 1u), q1 = pp.win[k], q2 = q1 + pp.ww;
+        const uint32_t lenbud = s_lenbud[seg];
+        const int rlen = (int)(lenbud & 0xFFFFu);
+        const int nl = q1 < 8 ? q1 : 8;                                       // bases left of the window
+        const int nr = rlen - q2 < 8 ? (rlen - q2 < 0 ? 0 : rlen - q2) : 8;   // bases right of it
+        const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) | ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
         const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
         int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
         const int tcap = left + right;  // target length, saturated (exact below 65535)
@@ -681,18 +690,18 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
         bool ok = q1 <= left;                  // p = jx - q1 >= 0
         if (left == 0) ok = ok && fit0;        // window at target position 0: pos-0 path
         else ok = ok && (rlen - q1 <= right);  // p + len <= T
-        const uint32_t x = cx.rfl ^ ent.w;
-        const uint32_t d = (x | (x >> 1)) & 0x55555555u & cx.fmask;
-        ok = ok && ((uint32_t)__popc(d) <= (cx.lenbud >> 16));
+        const uint32_t x = s_rfl[seg] ^ ent.w;
+        const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
+        ok = ok && ((uint32_t)__popc(d) <= (lenbud >> 16));
         if (!ok) continue;
         const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
         const uint32_t pos_ok = left < 65535 ? 1u : 0u;
         const uint32_t slot = atomicAdd(&s_tilecnt, 1u);
         if (slot < room)
-          desc[base + slot] = make_uint4(tile * TILE + cx.owner, ent.y - (uint32_t)q1,
+          desc[base + slot] = make_uint4(tile * TILE + (seg >> 1), ent.y - (uint32_t)q1,
                                          (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
       }
-      __syncthreads();  // s_ctx / s_pref / s_own are reused by the next chunk
+      __syncthreads();  // the LDS tables are reused by the next chunk
     }
     nvalid += __popc(valid);
     if (active) rvalid[i] = valid;
@@ -1726,9 +1735,9 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     c->force_exact_blocks = false;
     return rc;
   }
-  c->stats.ms_seed = tm.total(0);
+  c->stats.ms_screen = tm.total(0);
   c->stats.ms_scan = tm.total(1);
-  c->stats.ms_expand = tm.total(2);
+  c->stats.ms_unused0 = tm.total(2);
   c->stats.ms_confirm = tm.total(3);
   c->stats.ms_select = tm.total(4);
   (void)hipEventElapsedTime(&c->stats.ms_total, ev0, ev1);
