@@ -29,6 +29,16 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # same guide: 6.29 TB/s measured float4 copy
 
 
+def measured_traffic(workload_key):
+    """HBM bytes per k_confirm launch from the PMC passes recorded under profiles/ (rocprofv3
+    --pmc cannot run inside this process); None if no record matches the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f)[workload_key]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(wl, cfg, targets_ascii, reads_ascii, eng_factory, n_raw_full, log):
     """Reference-shaped CPU port (oracle/literal.cpp: Bloom + rolling-hash screen, sorted
     merge-join confirm) timed on a bounded sample, plus a bit-exactness check of the GPU path on
@@ -246,7 +256,7 @@ def main() -> int:
             "roofline": {
                 "kernel": "k_confirm", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-                "traffic": None, "bytes_per_pair": bytes_launch / max(st["n_pairs"] / max(st["confirm_launches"], 1), 1),
+                "traffic": measured_traffic(args.workload) if not args.reads else None, "bytes_per_pair": bytes_launch / max(st["n_pairs"] / max(st["confirm_launches"], 1), 1),
                 "pairs_per_launch": st["n_pairs"] / max(st["confirm_launches"], 1),
                 "avg_launch_ms": ms_launch, "launches_per_step": st["confirm_launches"],
             },
