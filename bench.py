@@ -129,11 +129,19 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         return 3
+    # Rehearsal knobs (never set by the driver): run N ranks on ONE card over gloo to exercise
+    # the N>1 control flow where only one GPU exists (RCCL refuses two ranks on one device).
+    backend = os.environ.get("MUSC_BENCH_BACKEND", "nccl")
+    if "MUSC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MUSC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     wl = synth.WORKLOADS[args.workload]
     if args.reads:
@@ -185,7 +193,7 @@ def main() -> int:
             h = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
             if n:
                 eng.hits_to(h.data_ptr(), n, True)
-            g = gather_hits(h[:n], read_base, dst=0)
+            g = gather_hits(h[:n] if backend == "nccl" else h[:n].cpu(), read_base, dst=0)
             if g is not None:
                 gathered_n[0] = int(g.shape[0])
         else:
@@ -193,6 +201,7 @@ def main() -> int:
         return n
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -213,7 +222,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = eng.stats()

@@ -7,12 +7,13 @@
 //   select : cmd/muscato_combine_windows/main.go:36-60 (per-read best + MMTol)
 //
 // MI355X design: the target database stays resident in HBM as one 2-bit
-// stream plus a k-mer -> (gene, offset) CSR index built once per (database, WindowWidth);
-// reads are fixed-stride 2-bit records.  One pass = k_seed (window keys -> index buckets)
-// -> scan -> k_expand (candidate pairs) -> k_confirm (XOR/popcount Hamming distance,
-// HBM-bound) -> k_select (per-read best + MMTol, compaction).  The Bloom sketch of the
-// reference only prunes work and cannot change results (SURVEY.md 8a note H): every
-// candidate is verified exactly in k_confirm, including its window key.
+// stream plus a k-mer -> (gene, offset) table of 64-byte buckets built once per (database,
+// WindowWidth); reads are fixed-stride 2-bit records.  One pass = k_screen (window keys probe
+// the table, candidates filtered from the index entry alone) -> k_confirm (XOR/popcount Hamming
+// distance, HBM-bound) -> k_select -> scan -> k_emit (per-read best + MMTol, tuples in read
+// order).  The Bloom sketch of the reference only prunes work and cannot change results
+// (SURVEY.md 8a note H): every candidate is verified exactly in k_confirm, including its
+// window key.
 //
 // There is no CPU fallback in this library.
 
