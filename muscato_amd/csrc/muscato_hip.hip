@@ -403,16 +403,25 @@ struct Rec {
     }
   }
   DEV uint32_t len() const { return w[RW - 1] & 0xFFFFu; }
-  // 64 bits from bit offset bo (bo is wave-uniform in every caller: selects, no scratch)
+  // 64 bits from bit offset bo.  bo is wave-uniform in every caller, so the word index is
+  // resolved by a scalar branch and each case names its registers statically (a chain of
+  // per-word selects costs 3*RW VALU per call instead).
   DEV uint64_t ext(uint32_t bo) const {
-    const int i = (int)(bo >> 5);
     const uint32_t sh = bo & 31u;
     uint32_t a = 0, b = 0, c = 0;
-#pragma unroll
-    for (int j = 0; j < RW; j++) {
-      a = (j == i) ? w[j] : a;
-      b = (j == i + 1) ? w[j] : b;
-      c = (j == i + 2) ? w[j] : c;
+    switch (__builtin_amdgcn_readfirstlane((int)(bo >> 5))) {
+#define MUSC_EXT_CASE(I)                                             \
+  case I:                                                            \
+    a = w[I < RW ? I : 0];                                           \
+    b = (I + 1 < RW) ? w[I + 1 < RW ? I + 1 : 0] : 0u;               \
+    c = (I + 2 < RW) ? w[I + 2 < RW ? I + 2 : 0] : 0u;               \
+    break;
+      MUSC_EXT_CASE(0) MUSC_EXT_CASE(1) MUSC_EXT_CASE(2) MUSC_EXT_CASE(3)
+      MUSC_EXT_CASE(4) MUSC_EXT_CASE(5) MUSC_EXT_CASE(6) MUSC_EXT_CASE(7)
+      MUSC_EXT_CASE(8) MUSC_EXT_CASE(9) MUSC_EXT_CASE(10) MUSC_EXT_CASE(11)
+      MUSC_EXT_CASE(12) MUSC_EXT_CASE(13) MUSC_EXT_CASE(14) MUSC_EXT_CASE(15)
+#undef MUSC_EXT_CASE
+      default: break;
     }
     const uint64_t lo = (uint64_t)a | ((uint64_t)b << 32);
     return sh ? (lo >> sh) | ((uint64_t)c << (64 - sh)) : lo;
@@ -439,6 +448,7 @@ DEV uint32_t rec_flank_left(const R& r, uint32_t base) {
 template <class R>
 DEV uint32_t rec_bucket(const R& r, const R& m, bool has_m, uint32_t q1, int ww, int bits, int direct) {
   const int nb = 2 * ww;
+  if (direct && !has_m) return (uint32_t)(__brevll(r.ext(2 * q1) & lowmask64(nb)) >> (64 - nb));
   uint64_t h = 0, anymask = 0, key0 = 0;
   for (int c = 0; c < nb; c += 64) {
     const int take = nb - c < 64 ? nb - c : 64;
@@ -456,27 +466,26 @@ DEV uint32_t rec_bucket(const R& r, const R& m, bool has_m, uint32_t q1, int ww,
 // 5-letter alphabet {A,C,G,T,other}; the count does not depend on how letters are numbered.
 template <class R>
 DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww) {
-  uint32_t seen = 0;
+  uint32_t seen25 = 0, seen16 = 0;  // pairs with / without an X involved
   for (int c = 0; c + 1 < ww; c += 31) {  // 32-base chunks overlapping by one base
     const int nbase = ww - c < 32 ? ww - c : 32;
     const uint64_t key = r.ext(2 * (q1 + c));
     const uint64_t mk = has_m ? (m.ext(2 * (q1 + c)) & lowmask64(2 * nbase)) : 0ull;
     if (mk == 0) {
       // no X in the chunk: a pair of bases is a 4-bit code, 16 possible pairs
-      uint32_t s16 = 0;
-      for (int i = 0; i + 1 < nbase; i++) s16 |= 1u << ((uint32_t)(key >> (2 * i)) & 15u);
-      // map the 16-bit set of (a + 4b) onto the 25-bit set of (a*5 + b)
-      for (int q = 0; q < 16; q++)
-        if ((s16 >> q) & 1u) seen |= 1u << ((q & 3) * 5 + (q >> 2));
+      for (int i = 0; i + 1 < nbase; i++) seen16 |= 1u << ((uint32_t)(key >> (2 * i)) & 15u);
     } else {
       for (int i = 0; i + 1 < nbase; i++) {
         const uint32_t a = ((mk >> (2 * i)) & 1u) ? 4u : ((uint32_t)(key >> (2 * i)) & 3u);
         const uint32_t b = ((mk >> (2 * i + 2)) & 1u) ? 4u : ((uint32_t)(key >> (2 * i + 2)) & 3u);
-        seen |= 1u << (a * 5 + b);
+        seen25 |= 1u << (a * 5 + b);
       }
     }
   }
-  return __popc(seen);
+  if (seen25 == 0) return __popc(seen16);  // the usual case: distinct pairs over {A,C,G,T}
+  for (int q = 0; q < 16; q++)  // merge: pair code a + 4b -> a*5 + b
+    if ((seen16 >> q) & 1u) seen25 |= 1u << ((q & 3) * 5 + (q >> 2));
+  return __popc(seen25);
 }
 
 // per-pair result word: bits 0-15 mismatch count, bit 16 NX_DUP, bits 20-23 window,
