@@ -385,6 +385,7 @@ struct PathParams {
   int32_t mmtol;
   int32_t apply_mmtol;
   uint32_t q1zero_mask;  // windows whose start is 0 (the pos-0 path of processSeq)
+  int32_t dbg;           // experiments only (MUSC_DEBUG_SCREEN): 1 skip flat phase, 2 skip bucket loads, 4 skip desc writes
 };
 
 // A read record: RW u32 words, bases (2 bits each) in words 0..RW-2, length in word RW-1.
@@ -497,8 +498,6 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 #define WB_NONE 0xFFFFFFFFu
 
 #define TILE 256  // reads per tile = threads per workgroup of k_screen
-#define EXP_STAGE 4
-#define EXP_POOL 256
 
 // k_screen -- muscato_screen + the join, fused: one workgroup per tile of 256 reads, one
 // thread per read.  For each window of the read that takes part
@@ -513,12 +512,11 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // k-mer hits are about half of all candidates).  The flank test never over-counts: an X is
 // stored as code 0 on both sides.
 //
-// Survivors: the first 4 descriptors of a thread wait in LDS (a shared pool takes the rest);
-// after a workgroup scan of the counts the tile takes the next range of its workgroup's own
-// region of `desc` (region = desc_cap / gridDim descriptors: no atomics -- one shared cursor
-// would serialise ~60 k single-address atomics per launch at ~11 ns each) and the threads copy
-// their descriptors in read order.  A tile's pairs are contiguous, a read's pairs adjacent;
-// nothing downstream depends on where a tile's range lies (k_emit orders the tuples by read).
+// Survivors are appended (LDS counter) to the tile's range inside the workgroup's own region
+// of `desc` (region = desc_cap / gridDim descriptors, so no global cursor is needed).  A tile's
+// pairs are contiguous and roughly in (read, window) order, which keeps k_confirm's record
+// loads local; nothing downstream needs more than that (k_select / k_emit work per tile in LDS
+// and k_emit orders the tuples by read).
 //
 // Descriptor (16 B): x = read index within the batch, y = global base offset of the
 // placement, z = window | z-flag << 4 | pos_ok << 5 | position in the target << 6 (when it
@@ -526,18 +524,6 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // counters: [0] valid windows, [3] candidates (index entries walked), [4] pairs,
 //           [7] the largest number of descriptors any workgroup needed (region size to retry with).
 #define SCR_OWN 2048  // flat items per chunk whose owner is looked up directly
-
-// context of one (read, window) probe while its bucket entries are being tested
-struct __attribute__((aligned(16))) ScrCtx {
-  uint32_t bucket;  // index into T
-  uint32_t ovf;     // start of the bucket's overflow list in E
-  uint32_t rfl;     // the read's own 8+8 flanking bases around this window
-  uint32_t fmask;   // which of them exist
-  uint32_t lenbud;  // read length | mismatch budget << 16
-  uint32_t kq1;     // window index | window start << 8
-  uint32_t owner;   // thread (= read of the tile)
-  uint32_t pad;
-};
 
 template <int RW>
 __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd,
@@ -646,7 +632,7 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
           const uint32_t b = __shfl(bb[j], src);
           const int pt = __shfl((int)part[j], src);
           uint4 v = make_uint4(0, 0, 0, 0);
-          if (pt) v = reinterpret_cast<const uint4*>(T + b)[lane & 3];
+          if (pt && !(pp.dbg & 2)) v = reinterpret_cast<const uint4*>(T + b)[lane & 3];
           s_bkt[2 * (wid * 64 + src) + j][lane & 3] = v;
         }
       }
@@ -669,7 +655,7 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
       }
       __syncthreads();
       // ---- phase B: the chunk's entries as one flat list, in (read, window, entry) order
-      for (uint32_t t = threadIdx.x; t < total; t += TILE) {
+      for (uint32_t t = threadIdx.x; t < ((pp.dbg & 1) ? 0u : total); t += TILE) {
         uint32_t seg;
         if (t < SCR_OWN) {
           seg = s_own[t];
@@ -707,7 +693,7 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
         const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
         const uint32_t pos_ok = left < 65535 ? 1u : 0u;
         const uint32_t slot = atomicAdd(&s_tilecnt, 1u);
-        if (slot < room)
+        if (slot < room && !(pp.dbg & 4))
           desc[base + slot] = make_uint4(tile * TILE + (seg >> 1), ent.y - (uint32_t)q1,
                                          (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
       }
@@ -989,11 +975,6 @@ __global__ void k_block_overflow(const uint32_t* __restrict__ block_table, uint3
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << BLOCK_TABLE_BITS); i += gridDim.x * blockDim.x)
     c += block_table[i] > max_matches;
   block_add_u64(c, &counters[5]);
-}
-
-__global__ void k_rebase_hits(musc_hit* h, uint64_t n, uint32_t add) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) h[i].read_idx += add;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1588,6 +1569,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   pp.direct = c->idx_direct;
   pp.mmtol = P->mmtol > 0xFFFF ? 0xFFFF : P->mmtol;
   pp.apply_mmtol = P->apply_mmtol;
+  if (const char* dv = getenv("MUSC_DEBUG_SCREEN")) pp.dbg = atoi(dv);
   for (int k = 0; k < pp.W; k++) {
     pp.win[k] = P->windows[k];
     if (P->windows[k] == 0) pp.q1zero_mask |= 1u << k;
