@@ -72,7 +72,11 @@ typedef struct {
   int32_t max_mismatch_p1;
   /* 1 = skip the per-block MaxMatches check (musc_stats.n_overflow_blocks becomes ~0) */
   int32_t skip_block_check;
-  int32_t reserved[3];
+  /* > 1 when this context only sees 1/n_shards of the reads of a (window,key) block: the
+   * MaxMatches check then uses MaxMatches / n_shards, so that "no overflow on any shard"
+   * proves "no overflow" (SURVEY.md 8e caveat) */
+  int32_t n_shards;
+  int32_t reserved[2];
 } musc_params;
 
 /* Counters and device timings of the last musc_match* call on a context. */
@@ -147,6 +151,15 @@ int musc_match(musc_ctx* ctx, const musc_params* params, musc_hit** hits, uint64
 void musc_free_hits(musc_hit* hits);
 
 int musc_get_stats(musc_ctx* ctx, musc_stats* out);
+
+/* When the last musc_match* left n_overflow_blocks > 0: the (read, window) probes whose
+ * (window, key) block may hold more than MaxMatches accepted pairs -- the blocks for which
+ * cmd/muscato_confirm/main.go:233-242, 424-448 keep an order-dependent subset.  The library
+ * returns every accepted tuple; a host that must reproduce the truncation literally re-derives
+ * those blocks from this list (muscato_host.hpp: apply_maxmatches).  Arrays are library-owned
+ * until musc_free_u32(); n = 0 when nothing overflowed. */
+int musc_overflow_probes(musc_ctx* ctx, uint32_t** read_idx, uint32_t** window, uint64_t* n);
+void musc_free_u32(uint32_t* p);
 
 /* ---- several GPUs in one process (a Go host driving one ctx per GPU from locked threads):
  * concatenate the device-resident hits of ctxs[0..n) in rank order into one host array,

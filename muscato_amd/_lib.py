@@ -29,7 +29,8 @@ class MuscParams(ctypes.Structure):
         ("apply_mmtol", ctypes.c_int32),
         ("max_mismatch_p1", ctypes.c_int32),
         ("skip_block_check", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 3),
+        ("n_shards", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -52,7 +53,7 @@ SYMBOLS = [
     "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
     "musc_reads_load_ascii", "musc_reads_load_packed",
     "musc_match_device", "musc_hits_copy", "musc_match", "musc_free_hits",
-    "musc_get_stats", "musc_gather",
+    "musc_get_stats", "musc_gather", "musc_overflow_probes", "musc_free_u32",
 ]
 
 _lib = None
@@ -89,6 +90,10 @@ def load() -> ctypes.CDLL:
     lib.musc_free_hits.argtypes = [vp]
     lib.musc_free_hits.restype = None
     lib.musc_get_stats.argtypes = [vp, ctypes.POINTER(MuscStats)]
+    lib.musc_overflow_probes.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.musc_overflow_probes.restype = ctypes.c_int
+    lib.musc_free_u32.argtypes = [vp]
+    lib.musc_free_u32.restype = None
     lib.musc_gather.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(u64),
                                 ctypes.POINTER(vp), ctypes.POINTER(u64)]
     for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",

@@ -241,6 +241,20 @@ class Engine:
             self.hits_to(out.ctypes.data, n, False)
         return out
 
+    def overflow_probes(self) -> np.ndarray:
+        """(read_idx, window) of the probes whose (window,key) block may exceed MaxMatches after
+        the last match (empty when n_overflow_blocks == 0).  uint32 [n, 2]."""
+        pr, pw, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        self._check(self._lib.musc_overflow_probes(self._h, ctypes.byref(pr), ctypes.byref(pw), ctypes.byref(n)),
+                    "musc_overflow_probes")
+        out = np.zeros((n.value, 2), dtype=np.uint32)
+        if n.value:
+            out[:, 0] = np.ctypeslib.as_array(ctypes.cast(pr, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value,))
+            out[:, 1] = np.ctypeslib.as_array(ctypes.cast(pw, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value,))
+        self._lib.musc_free_u32(pr)
+        self._lib.musc_free_u32(pw)
+        return out
+
     def stats(self) -> dict:
         s = _lib.MuscStats()
         self._check(self._lib.musc_get_stats(self._h, ctypes.byref(s)), "musc_get_stats")

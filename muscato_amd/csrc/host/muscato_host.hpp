@@ -710,6 +710,7 @@ inline musc_params to_params(const Config& c) {
   p.mmtol = c.MMTol;
   p.apply_mmtol = 1;
   p.max_mismatch_p1 = c.MaxMismatch >= 0 ? c.MaxMismatch + 1 : 0;
+  p.n_shards = c.GPUs > 1 ? c.GPUs : 0;
   return p;
 }
 
@@ -728,6 +729,173 @@ inline Concat concat(It b, It e, F seq_of) {
   }
   c.buf.append(16, '\0');
   return c;
+}
+
+// utils/entropy.go:5-40 on ASCII
+inline int count_dinuc(const char* seq, int n) {
+  bool seen[25] = {false};
+  int last = 0, cnt = 0;
+  for (int i = 0; i < n; i++) {
+    int v;
+    switch (seq[i]) { case 'A': v = 0; break; case 'T': v = 1; break; case 'G': v = 2; break; case 'C': v = 3; break; default: v = 4; }
+    if (i > 0 && !seen[5 * last + v]) { seen[5 * last + v] = true; cnt++; }
+    last = v;
+  }
+  return cnt;
+}
+
+// The reference truncates a (window, key) block of muscato_confirm at MaxMatches accepted pairs
+// in an order-dependent way (cmd/muscato_confirm/main.go:183-244: candidates in the bytewise
+// order of their smatch_k line outside, reads in the bytewise order of their win_k_sorted line
+// inside; "first": append and stop once len > MaxMatches; "best": qinsert :424-448, a sift-up
+// heap whose array tail is cut at MaxMatches).  The GPU path returns every accepted tuple and
+// says which probes sit in blocks that may overflow; this re-derives those blocks from the
+// tuples and replays the truncation literally, then rebuilds the union over windows
+// (cmd/muscato/main.go:441-463) for the affected reads.  `all` = every accepted tuple
+// (apply_mmtol = 0).  Returns the corrected set of all accepted tuples.
+inline std::vector<musc_hit> apply_maxmatches(const Config& cfg, const std::vector<UniqueRead>& reads,
+                                              const std::vector<std::string>& targets, std::vector<musc_hit> all,
+                                              const uint32_t* probe_read, const uint32_t* probe_win, uint64_t nprobes,
+                                              size_t* n_truncated_blocks) {
+  const int ww = cfg.WindowWidth, W = (int)cfg.Windows.size();
+  if (n_truncated_blocks) *n_truncated_blocks = 0;
+  auto valid = [&](uint32_t r, int k) {
+    const std::string& s = reads[r].seq;
+    const int q1 = cfg.Windows[k], q2 = q1 + ww;
+    return (int)s.size() >= q2 && count_dinuc(s.data() + q1, ww) >= cfg.MinDinuc;
+  };
+  // would window k's confirm emit tuple h (D2-D4 of SURVEY.md 8a)
+  auto emits = [&](const musc_hit& h, int k) {
+    if (!valid(h.read_idx, k)) return false;
+    const std::string& s = reads[h.read_idx].seq;
+    const std::string& t = targets[h.gene_idx];
+    const int64_t q1 = cfg.Windows[k], jx = (int64_t)h.pos + q1, L = (int64_t)s.size(), T = (int64_t)t.size();
+    if (jx + ww > T || memcmp(s.data() + q1, t.data() + jx, ww) != 0) return false;
+    if (jx == 0) return L <= std::min<int64_t>(100 - ww, T);
+    return (int64_t)h.pos + L <= T;
+  };
+  std::sort(all.begin(), all.end(), [](const musc_hit& a, const musc_hit& b) {
+    if (a.read_idx != b.read_idx) return a.read_idx < b.read_idx;
+    if (a.gene_idx != b.gene_idx) return a.gene_idx < b.gene_idx;
+    return a.pos < b.pos;
+  });
+  std::vector<size_t> first_of(reads.size() + 1, all.size());
+  for (size_t i = all.size(); i-- > 0;) first_of[all[i].read_idx] = i;
+  for (size_t r = reads.size(); r-- > 0;) if (first_of[r] == all.size()) first_of[r] = first_of[r + 1];
+
+  // candidate blocks named by the probes
+  typedef std::pair<int, std::string> BlockId;
+  std::map<BlockId, std::vector<uint32_t>> block_reads;
+  for (uint64_t i = 0; i < nprobes; i++) {
+    const int k = (int)probe_win[i];
+    if (k >= W || probe_read[i] >= reads.size() || !valid(probe_read[i], k)) continue;
+    block_reads[BlockId(k, reads[probe_read[i]].seq.substr(cfg.Windows[k], ww))];
+  }
+  if (block_reads.empty()) return all;
+  for (uint32_t r = 0; r < reads.size(); r++)
+    for (int k = 0; k < W; k++) {
+      if (!valid(r, k)) continue;
+      auto it = block_reads.find(BlockId(k, reads[r].seq.substr(cfg.Windows[k], ww)));
+      if (it != block_reads.end()) it->second.push_back(r);
+    }
+
+  struct Key3 { uint32_t r, g, p; bool operator<(const Key3& o) const { return r != o.r ? r < o.r : g != o.g ? g < o.g : p < o.p; } };
+  std::map<BlockId, std::set<Key3>> kept;  // only for blocks that really overflow
+  for (auto& br : block_reads) {
+    const int k = br.first.first, q1 = cfg.Windows[k], q2 = q1 + ww;
+    std::vector<uint32_t>& R = br.second;
+    // reads in the order of their "key \t left \t right" line (cmd/muscato/main.go:261-270)
+    std::sort(R.begin(), R.end(), [&](uint32_t a, uint32_t b) {
+      const std::string &x = reads[a].seq, &y = reads[b].seq;
+      return x.substr(0, q1) + "\t" + x.substr(q2) < y.substr(0, q1) + "\t" + y.substr(q2);
+    });
+    // accepted pairs of this block, grouped by candidate (gene, window start)
+    std::map<std::pair<uint32_t, uint32_t>, std::map<uint32_t, uint32_t>> by_cand;  // cand -> read -> nx
+    size_t npairs = 0;
+    for (uint32_t r : R)
+      for (size_t i = first_of[r]; i < first_of[r + 1]; i++)
+        if (emits(all[i], k)) {
+          by_cand[std::make_pair(all[i].gene_idx, all[i].pos + (uint32_t)q1)][r] = all[i].nmiss;
+          npairs++;
+        }
+    if ((int64_t)npairs <= (int64_t)cfg.MaxMatches) continue;  // a hash-collision false alarm
+    if (n_truncated_blocks) ++*n_truncated_blocks;
+    // candidates in the order of their "key \t left \t right \t %011d \t pos" line
+    // (cmd/muscato_screen/main.go:303-316, 341-363; cmd/muscato/main.go:341-350)
+    struct Cand { std::string line; uint32_t g, jx; };
+    std::vector<Cand> C;
+    for (auto& c : by_cand) {
+      const std::string& t = targets[c.first.first];
+      const int64_t jx = c.first.second, T = (int64_t)t.size();
+      std::string left, right;
+      if (jx == 0) {
+        right = t.substr(ww, std::max<int64_t>(std::min<int64_t>(100 - q2, T) - ww, 0));
+      } else {
+        left = t.substr(jx - q1, q1);
+        const int64_t jy = jx + ww, jz = std::min<int64_t>(jy + cfg.MaxReadLength - q2, T);
+        right = t.substr(jy, std::max<int64_t>(jz - jy, 0));
+      }
+      char gid[16];
+      snprintf(gid, sizeof gid, "%011u", c.first.first);
+      C.push_back(Cand{left + "\t" + right + "\t" + gid + "\t" + std::to_string(jx), c.first.first, c.first.second});
+    }
+    std::sort(C.begin(), C.end(), [](const Cand& a, const Cand& b) { return a.line < b.line; });
+    struct Q { int mm; Key3 t; };
+    std::vector<Q> q;
+    const bool first = cfg.MatchMode == "first";
+    bool stop = false;
+    for (auto& c : C) {
+      const auto& acc = by_cand[std::make_pair(c.g, c.jx)];
+      for (uint32_t r : R) {
+        auto it = acc.find(r);
+        if (it == acc.end()) continue;
+        Q qq{(int)it->second, Key3{r, c.g, c.jx - (uint32_t)q1}};
+        if (first) {
+          q.push_back(qq);
+          if ((int64_t)q.size() > (int64_t)cfg.MaxMatches) { stop = true; break; }  // :236-238
+        } else {
+          q.push_back(qq);  // qinsert :424-448
+          size_t ii = q.size() - 1;
+          while (ii > 0) {
+            const size_t jj = (ii - 1) / 2;
+            if (q[jj].mm > q[ii].mm) { std::swap(q[jj], q[ii]); ii = jj; } else break;
+          }
+          if ((int64_t)q.size() > (int64_t)cfg.MaxMatches) q.resize(cfg.MaxMatches);
+        }
+      }
+      if (stop) break;
+    }
+    std::set<Key3>& ks = kept[br.first];
+    for (auto& e : q) ks.insert(e.t);
+  }
+  if (kept.empty()) return all;
+
+  // rebuild the union for every read that has a window in a truncated block
+  std::vector<char> affected(reads.size(), 0);
+  for (auto& kb : kept)
+    for (uint32_t r : block_reads[kb.first]) affected[r] = 1;
+  std::vector<musc_hit> out;
+  out.reserve(all.size());
+  for (const musc_hit& h : all) {
+    if (!affected[h.read_idx]) { out.push_back(h); continue; }
+    bool survive = false;
+    for (int k = 0; k < W && !survive; k++) {
+      if (!emits(h, k)) continue;
+      auto it = kept.find(BlockId(k, reads[h.read_idx].seq.substr(cfg.Windows[k], ww)));
+      survive = it == kept.end() || it->second.count(Key3{h.read_idx, h.gene_idx, h.pos});
+    }
+    if (survive) out.push_back(h);
+  }
+  return out;
+}
+
+// per read keep nmiss <= best + MMTol (cmd/muscato_combine_windows/main.go:36-60)
+inline std::vector<musc_hit> best_filter(const std::vector<musc_hit>& all, size_t nreads, int mmtol) {
+  std::vector<uint32_t> best(nreads, 0xFFFFFFFFu);
+  for (auto& h : all) best[h.read_idx] = std::min(best[h.read_idx], h.nmiss);
+  std::vector<musc_hit> out;
+  for (auto& h : all) if (h.nmiss <= best[h.read_idx] + (uint32_t)mmtol) out.push_back(h);
+  return out;
 }
 
 // Load the targets, shard the unique reads over cfg.GPUs devices (one host thread + one
@@ -779,6 +947,40 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
                  (unsigned long long)s.n_hits, s.ms_total, s.ms_screen, s.ms_scan, s.ms_confirm, s.ms_select,
                  s.ms_index_build, s.ms_confirm > 0 ? s.confirm_bytes / 1e6 / s.ms_confirm : 0.0);
     }
+  }
+  bool overflow = false;
+  for (int g = 0; g < G && err.empty(); g++) {
+    musc_stats s;
+    musc_get_stats(ctxs[g], &s);
+    overflow = overflow || (s.n_overflow_blocks != 0 && s.n_overflow_blocks != ~0ull);
+  }
+  for (int g = 1; g < G; g++) if (ctxs[g]) { musc_destroy(ctxs[g]); ctxs[g] = nullptr; }
+  if (err.empty() && overflow) {
+    // Some (window,key) block may exceed MaxMatches: redo the pass on one GPU with every read,
+    // take all accepted tuples and replay the reference's truncation on the host.
+    fputs("MaxMatches reached in at least one window-key block: replaying the reference's truncation...\n", stderr);
+    musc_ctx* c = ctxs[0];
+    musc_params P1 = P;
+    P1.apply_mmtol = 0;
+    P1.n_shards = 0;
+    const Concat rd = concat(reads.begin(), reads.end(), [](const UniqueRead& u) -> const std::string& { return u.seq; });
+    musc_hit* h = nullptr;
+    uint64_t n = 0, np = 0;
+    uint32_t *pr = nullptr, *pw = nullptr;
+    if (musc_reads_load_ascii(c, rd.buf.data(), rd.off.data(), reads.size(), 0) || musc_match(c, &P1, &h, &n) ||
+        musc_overflow_probes(c, &pr, &pw, &np)) {
+      err = musc_last_error(c);
+    } else {
+      size_t ntrunc = 0;
+      std::vector<musc_hit> all(h, h + n);
+      all = apply_maxmatches(cfg, reads, targets, std::move(all), pr, pw, np, &ntrunc);
+      out = best_filter(all, reads.size(), cfg.MMTol);
+      log.printf("MaxMatches: %llu suspect probes, %zu blocks truncated as the reference does", (unsigned long long)np, ntrunc);
+      if (stats0) stats0->n_overflow_blocks = 0;  // handled exactly
+    }
+    musc_free_hits(h);
+    musc_free_u32(pr);
+    musc_free_u32(pw);
   }
   for (auto c : ctxs) if (c) musc_destroy(c);
   if (!err.empty()) throw Die(1, "muscato hot path failed:\n" + err);

@@ -962,6 +962,37 @@ __global__ __launch_bounds__(TILE) void k_emit(uint64_t r0, uint32_t n, const ui
   }
 }
 
+// After an exact (mode 2) pass: the (read, window) probes whose (window, key) block counter is
+// above MaxMatches -- the blocks the reference would have truncated.  One thread per read.
+template <int RW>
+__global__ __launch_bounds__(256) void k_hot_probes(const uint32_t* __restrict__ rd,
+                                                    const uint32_t* __restrict__ rdm, uint64_t nreads,
+                                                    int rw_rt, PathParams pp,
+                                                    const uint32_t* __restrict__ block_table,
+                                                    uint32_t max_matches, uint2* __restrict__ out,
+                                                    uint64_t cap, unsigned long long* __restrict__ cursor) {
+  const int rw = RW ? RW : rw_rt;
+  const bool has_m = rdm != nullptr;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nreads; i += (uint64_t)gridDim.x * blockDim.x) {
+    Rec<RW> rec;
+    rec.load(rd + i * (uint64_t)rw, rw);
+    Rec<RW> recm = rec;
+    if (has_m) recm.load(rdm + i * (uint64_t)rw, rw);
+    const uint32_t len = rec.len();
+    for (int k = 0; k < pp.W; k++) {
+      const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
+      if (len < q2) continue;
+      if (pp.min_dinuc > 0 && rec_count_dinuc(rec, recm, has_m, q1, pp.ww) < pp.min_dinuc) continue;
+      const uint32_t b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+      const uint64_t h = mix64(((uint64_t)k << 32) | b);
+      if (block_table[h >> (64 - BLOCK_TABLE_BITS)] > max_matches) {
+        const unsigned long long slot = atomicAdd(cursor, 1ull);
+        if (slot < cap) out[slot] = make_uint2((uint32_t)i, (uint32_t)k);
+      }
+    }
+  }
+}
+
 // counters[2] (hits so far) += hbase[n] (hits of this batch)
 __global__ void k_advance(const uint32_t* __restrict__ hbase, uint32_t n, unsigned long long* counters) {
   if (threadIdx.x == 0 && blockIdx.x == 0) counters[2] += hbase[n];
@@ -1032,6 +1063,9 @@ struct musc_ctx {
   DevBuf<uint16_t> nmiss_tab;
   DevBuf<uint32_t> block_table;
   bool force_exact_blocks = false;
+  PathParams last_pp;          // of the last musc_match_device
+  uint32_t last_max_matches = 0;
+  bool last_exact_blocks = false;  // block_table holds exact counters of that pass
   unsigned long long* counters = nullptr;  // [0] valid windows [1] accepted [2] hit cursor
   uint64_t* h_pinned = nullptr;            // 4 x u64 pinned staging
 
@@ -1597,7 +1631,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   HIPCHK(c, hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
   // MaxMatches accounting (see k_best_count): screening first, exact only if inconclusive
   const uint64_t planned_batches = (c->nreads + c->batch_reads - 1) / c->batch_reads + 1;
-  const uint64_t max_matches = P->max_matches > 0 ? (uint64_t)P->max_matches : 0x7FFFFFFFull;
+  uint64_t max_matches = P->max_matches > 0 ? (uint64_t)P->max_matches : 0x7FFFFFFFull;
+  if (P->n_shards > 1) max_matches /= (uint64_t)P->n_shards;  // this context sees one shard of each block
   const uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * MAX_GRID), 0x7FFFFFFFull);
   int block_mode = P->skip_block_check ? 0 : (c->force_exact_blocks || block_thr < 2 ? 2 : 1);
   const bool check_blocks = block_mode != 0;
@@ -1701,9 +1736,12 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     }
     r0 += n;
   }
+  c->last_pp = pp;
+  c->last_max_matches = (uint32_t)max_matches;
+  c->last_exact_blocks = block_mode == 2;
   if (block_mode == 2) {
     hipLaunchKernelGGL(k_block_overflow, dim3(1024), dim3(256), 0, c->stream, c->block_table.p,
-                       (uint32_t)(P->max_matches > 0 ? P->max_matches : 0x7FFFFFFF), c->counters);
+                       (uint32_t)max_matches, c->counters);
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipEventRecord(ev1, c->stream));
@@ -1776,6 +1814,64 @@ int musc_match(musc_ctx* c, const musc_params* P, musc_hit** hits, uint64_t* nhi
 }
 
 void musc_free_hits(musc_hit* hits) { free(hits); }
+
+int musc_overflow_probes(musc_ctx* c, uint32_t** read_idx, uint32_t** window, uint64_t* n) {
+  if (!c) return 1;
+  if (!read_idx || !window || !n) return fail(c, 2, "musc_overflow_probes: NULL output pointer");
+  *read_idx = *window = nullptr;
+  *n = 0;
+  if (c->stats.n_overflow_blocks == 0 || c->stats.n_overflow_blocks == ~0ull) return 0;
+  if (!c->last_exact_blocks || !c->block_table.p) return fail(c, 4, "no exact block counters from the last pass");
+  HIPCHK(c, hipSetDevice(c->device));
+  uint64_t cap = 1u << 20;
+  for (;;) {
+    uint2* d_out = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_out, cap * sizeof(uint2)));
+    HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8, c->stream));
+    const dim3 grid(std::min(nblk(c->nreads, 256), MAX_GRID)), block(256);
+    switch (c->rw) {
+      case 4: hipLaunchKernelGGL((k_hot_probes<4>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      case 8: hipLaunchKernelGGL((k_hot_probes<8>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      case 12: hipLaunchKernelGGL((k_hot_probes<12>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      case 16: hipLaunchKernelGGL((k_hot_probes<16>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      default: hipLaunchKernelGGL((k_hot_probes<0>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_pinned, c->counters + 8, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(d_out);
+      return fail(c, 10, "musc_overflow_probes: %s", hipGetErrorString(e));
+    }
+    const uint64_t found = c->h_pinned[0];
+    if (found > cap) {  // retry with room for all of them
+      (void)hipFree(d_out);
+      cap = found + 16;
+      continue;
+    }
+    std::vector<uint2> h(found ? found : 1);
+    if (found) e = hipMemcpy(h.data(), d_out, found * sizeof(uint2), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, 10, "musc_overflow_probes: %s", hipGetErrorString(e));
+    uint32_t* r = (uint32_t*)malloc(sizeof(uint32_t) * (found ? found : 1));
+    uint32_t* w = (uint32_t*)malloc(sizeof(uint32_t) * (found ? found : 1));
+    if (!r || !w) {
+      free(r);
+      free(w);
+      return fail(c, 7, "musc_overflow_probes: out of host memory");
+    }
+    for (uint64_t j = 0; j < found; j++) {
+      r[j] = h[j].x;
+      w[j] = h[j].y;
+    }
+    *read_idx = r;
+    *window = w;
+    *n = found;
+    return 0;
+  }
+}
+
+void musc_free_u32(uint32_t* p) { free(p); }
 
 int musc_get_stats(musc_ctx* c, musc_stats* out) {
   if (!c || !out) return 1;

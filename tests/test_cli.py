@@ -186,6 +186,47 @@ def test_cli_max_mismatch_addition(golden_dir, tmp_path):
     assert a == res
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,seed", [("first", 1), ("best", 1), ("first", 2), ("best", 3)])
+def test_cli_replays_maxmatches_truncation(tmp_path, mode, seed):
+    """cmd/muscato_confirm/main.go:233-242, 424-448: blocks with more than MaxMatches accepted
+    pairs are cut order-dependently.  The CLI must reproduce that cut exactly (GPU tuples +
+    host replay) -- expected output from the literal oracle."""
+    import json
+    import random
+    from oracle import literal
+    rng = random.Random(seed)
+    alpha = b"AC"  # two letters: every 4-mer key is shared by many reads and target positions
+    targets = [bytes(rng.choice(alpha) for _ in range(rng.randint(20, 40))) for _ in range(30)]
+    reads = sorted({bytes(rng.choice(alpha) for _ in range(rng.randint(10, 14))) for _ in range(25)})
+    ocfg = orc.Config(Windows=[0, 5], WindowWidth=4, PMatch=0.7, MinDinuc=0, MaxReadLength=50,
+                      MaxMatches=6, MMTol=2, MatchMode=mode)
+    with pytest.raises(OverflowError):
+        orc.match_direct(reads, targets, ocfg)  # the case really overflows
+    d = tmp_path
+    (d / "genes.txt").write_bytes(b"".join(b"g%d\t%s\n" % (i, t) for i, t in enumerate(targets)))
+    (d / "reads.fastq").write_bytes(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"F" * len(r)) for i, r in enumerate(reads)))
+    r = run([os.path.join(BIN, "muscato_prep_targets"), "genes.txt"], d)
+    assert r.returncode == 0, r.stderr
+    cfg = {"ReadFileName": "reads.fastq", "GeneFileName": "musc_genes.txt.sz", "GeneIdFileName": "musc_ids_genes.txt.sz",
+           "ResultsFileName": "result.txt", "Windows": [0, 5], "WindowWidth": 4, "PMatch": 0.7, "MinDinuc": 0,
+           "MaxReadLength": 50, "MaxMatches": 6, "MMTol": 2, "MatchMode": mode}
+    (d / "config.json").write_text(json.dumps(cfg))
+    r = run([os.path.join(BIN, "muscato"), "-ConfigFileName=config.json"], d)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"replaying the reference's truncation" in r.stderr
+    # expected: the literal oracle's union, then the reference's post-chain
+    seqs, ids = orc.prep_targets_file(str(d / "genes.txt"), False)
+    ureads = orc.uniqify(orc.prep_reads(orc.read_fastq((d / "reads.fastq").read_bytes()), ocfg))
+    hits = literal.match_literal([u.seq for u in ureads], seqs, ocfg, bloom_size=4000000, num_hash=20)
+    exp = orc.results_text(hits, ureads, seqs, ids, ocfg)
+    got = (d / "result.txt").read_bytes()
+    assert got == exp
+    # and it differs from what keeping every match would give
+    full = orc.results_text(orc.match_direct([u.seq for u in ureads], seqs, ocfg, check_overflow=False), ureads, seqs, ids, ocfg)
+    assert full != exp
+
+
 def test_cli_without_gpu_fails_loudly(golden_dir, tmp_path):
     """No GPU -> non-zero exit and a clear message, never a silent CPU path."""
     import ctypes

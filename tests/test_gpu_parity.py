@@ -228,11 +228,13 @@ def test_maxmatches_overflow_is_detected(eng):
     got = gpu_hits(eng, c, reads, targets, False)
     assert_same(got, as_arr(orc.match_direct(reads, targets, c, check_overflow=False)))
     assert eng.stats()["n_overflow_blocks"] >= 1
+    probes = eng.overflow_probes()
+    assert probes.tolist() == [[0, 0]]  # read 0 through window 0 sits in the overflowing block
     lit = literal.match_literal(reads, targets, c)
     assert set(map(tuple, lit)) < set(map(tuple, got.tolist()))   # the reference keeps a strict subset
     c.MaxMatches = 12                                              # exactly at the limit: no truncation
     got = gpu_hits(eng, c, reads, targets, False)
-    assert eng.stats()["n_overflow_blocks"] == 0
+    assert eng.stats()["n_overflow_blocks"] == 0 and len(eng.overflow_probes()) == 0
     assert_same(got, np.array(literal.match_literal(reads, targets, c), dtype=np.uint32).reshape(-1, 4))
     # two windows over the same placements: each window's block counts its own acceptances
     c = orc.Config(Windows=[0, 1], WindowWidth=4, PMatch=0.5, MaxReadLength=50, MaxMatches=11)
