@@ -29,7 +29,9 @@ def needs_build() -> bool:
 HOST = os.path.join(CSRC, "host")
 BIN = os.path.join(HERE, "bin")
 HOST_HEADERS = [os.path.join(HOST, "muscato_host.hpp"), os.path.join(HOST, "sz.hpp")]
-TOOLS = {"muscato": "muscato_cli.cpp", "muscato_prep_targets": "muscato_prep_targets.cpp"}
+TOOLS = {"muscato": "muscato_cli.cpp", "muscato_prep_targets": "muscato_prep_targets.cpp",
+         "muscato_screen": "muscato_screen.cpp", "muscato_confirm": "muscato_confirm.cpp"}
+GPU_TOOLS = ("muscato", "muscato_screen", "muscato_confirm")
 
 
 def build_tools(force: bool = False, verbose: bool = False) -> None:
@@ -42,7 +44,7 @@ def build_tools(force: bool = False, verbose: bool = False) -> None:
         if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
             continue
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-o", out, srcp, "-lz"]
-        if name == "muscato":
+        if name in GPU_TOOLS:
             cmd += ["-L" + HERE, "-lmuscato_hip", "-Wl,-rpath,$ORIGIN/.."]
         if verbose:
             print(" ".join(cmd))
