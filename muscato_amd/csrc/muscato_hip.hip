@@ -285,6 +285,52 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ 
   scan_store8(out, base, n, v);
 }
 
+// u64 variant of the scan for the overflow-list offsets of big databases (index build only;
+// plain element accesses, no tuning needed)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan64_block(const uint64_t* __restrict__ in,
+                                                            uint64_t* __restrict__ out,
+                                                            uint64_t* __restrict__ block_sums, uint64_t n) {
+  __shared__ uint64_t s_wave[SCAN_BLOCK / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint64_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = (base + i < n) ? in[base + i] : 0ull;
+    sum += v[i];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint64_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_wave[wid] = inc;
+  __syncthreads();
+  uint64_t wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_BLOCK / 64; w++) {
+    if (w < wid) wave_off += s_wave[w];
+    total += s_wave[w];
+  }
+  uint64_t run = wave_off + inc - sum;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < n) out[base + i] = run;  // exclusive
+    run += v[i];
+  }
+  if (block_sums && threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan64_add(uint64_t* __restrict__ out,
+                                                          const uint64_t* __restrict__ block_off, uint64_t n) {
+  const uint64_t add = block_off[blockIdx.x];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++)
+    if (base + i < n) out[base + i] += add;
+}
+
 // ------------------------------------------------------------------------------------
 // database index: a table of 64-byte buckets, one per k-mer key (direct) or key hash.
 //   Bucket = { count, cursor (build only), overflow start, 3 inline entries }.
@@ -294,7 +340,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ 
 //
 // One index entry (16 B, one dwordx4): everything k_screen needs about a window start
 // without touching the per-gene offset table.
-//   x gene   : target number
+//   x gene   : target number; databases of 2^32 bases or more ("wide"): gene in bits 0-23,
+//              bits 32-39 of the window start in bits 24-31
 //   y gposw  : global base offset of the window start (low 32 bits)
 //   z lr     : min(jx, 65535) | min(T - jx, 65535) << 16  (distances to the gene's two ends,
 //              saturated: window starts and read lengths are < 65535, so every comparison
@@ -321,42 +368,48 @@ template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_index(const uint32_t* __restrict__ db2,
                                                const uint32_t* __restrict__ dbm2,
                                                const uint64_t* __restrict__ seq_off, uint32_t nseq,
-                                               uint64_t nbases, int ww, int bits, int direct,
+                                               uint64_t nbases, int ww, int bits, int direct, int wide,
                                                Bucket* __restrict__ T, uint4* __restrict__ E) {
+  // one chunk of 256 consecutive bases per iteration (a dispatch holds fewer than 2^32
+  // work-items, so a thread per base cannot cover a database of 2^32 bases or more)
   __shared__ uint32_t s_g0;
-  const uint64_t gfirst = (uint64_t)blockIdx.x * blockDim.x;
-  if (threadIdx.x == 0) {
-    uint32_t lo = 0, hi = nseq;  // largest i < nseq with seq_off[i] <= gfirst
-    while (hi - lo > 1) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      if (seq_off[mid] <= gfirst) lo = mid; else hi = mid;
+  const uint64_t nchunks = (nbases + blockDim.x - 1) / blockDim.x;
+  for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint64_t gfirst = chunk * blockDim.x;
+    __syncthreads();  // the previous chunk's readers of s_g0 are done
+    if (threadIdx.x == 0) {
+      uint32_t lo = 0, hi = nseq;  // largest i < nseq with seq_off[i] <= gfirst
+      while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (seq_off[mid] <= gfirst) lo = mid; else hi = mid;
+      }
+      s_g0 = lo;
     }
-    s_g0 = lo;
-  }
-  __syncthreads();
-  const uint64_t g = gfirst + threadIdx.x;
-  if (g >= nbases) return;
-  uint32_t gene = s_g0;
-  while (seq_off[gene + 1] <= g) gene++;
-  const uint64_t s = seq_off[gene], e = seq_off[gene + 1];
-  const uint64_t jx = g - s;
-  if (jx + (uint64_t)ww > e - s) return;  // window would cross the target end
-  const uint32_t b = bucket_of(db2, dbm2, 2 * g, ww, bits, direct);
-  if (!SCATTER) {
-    atomicAdd(&T[b].count, 1u);
-  } else {
-    const uint32_t slot = atomicAdd(&T[b].cursor, 1u);
-    const uint64_t rem = e - g;  // T - jx
-    const uint32_t lr = (uint32_t)(jx > 65535 ? 65535 : jx) | ((uint32_t)(rem > 65535 ? 65535 : rem) << 16);
-    const uint32_t fl = flank_left(db2, g) | (((uint32_t)ext64(db2, 2 * (g + (uint64_t)ww)) & 0xFFFFu) << 16);
-    const uint4 ent = make_uint4(gene, (uint32_t)g, lr, fl);
-    if (slot < BUCKET_INLINE) T[b].e[slot] = ent;
-    else E[T[b].ovf + (slot - BUCKET_INLINE)] = ent;
+    __syncthreads();
+    const uint64_t g = gfirst + threadIdx.x;
+    if (g >= nbases) continue;
+    uint32_t gene = s_g0;
+    while (seq_off[gene + 1] <= g) gene++;
+    const uint64_t s = seq_off[gene], e = seq_off[gene + 1];
+    const uint64_t jx = g - s;
+    if (jx + (uint64_t)ww > e - s) continue;  // window would cross the target end
+    const uint32_t b = bucket_of(db2, dbm2, 2 * g, ww, bits, direct);
+    if (!SCATTER) {
+      atomicAdd(&T[b].count, 1u);
+    } else {
+      const uint32_t slot = atomicAdd(&T[b].cursor, 1u);
+      const uint64_t rem = e - g;  // T - jx
+      const uint32_t lr = (uint32_t)(jx > 65535 ? 65535 : jx) | ((uint32_t)(rem > 65535 ? 65535 : rem) << 16);
+      const uint32_t fl = flank_left(db2, g) | (((uint32_t)ext64(db2, 2 * (g + (uint64_t)ww)) & 0xFFFFu) << 16);
+      const uint4 ent = make_uint4(wide ? (gene | ((uint32_t)(g >> 32) << 24)) : gene, (uint32_t)g, lr, fl);
+      if (slot < BUCKET_INLINE) T[b].e[slot] = ent;
+      else E[T[b].ovf + (slot - BUCKET_INLINE)] = ent;
+    }
   }
 }
 
 // overflow list sizes: tmp[b] = max(count - 3, 0), scanned on the side, written back as ovf
-__global__ void k_index_ovf_count(const Bucket* __restrict__ T, uint64_t nb, uint32_t* __restrict__ tmp) {
+__global__ void k_index_ovf_count(const Bucket* __restrict__ T, uint64_t nb, uint64_t* __restrict__ tmp) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) {
     const uint32_t c = T[b].count;
@@ -366,7 +419,7 @@ __global__ void k_index_ovf_count(const Bucket* __restrict__ T, uint64_t nb, uin
   }
 }
 
-__global__ void k_index_ovf_set(Bucket* __restrict__ T, uint64_t nb, const uint32_t* __restrict__ tmp) {
+__global__ void k_index_ovf_set(Bucket* __restrict__ T, uint64_t nb, const uint64_t* __restrict__ tmp) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) T[b].ovf = tmp[b];
 }
@@ -385,6 +438,7 @@ struct PathParams {
   int32_t mmtol;
   int32_t apply_mmtol;
   uint32_t q1zero_mask;  // windows whose start is 0 (the pos-0 path of processSeq)
+  int32_t wide;          // database >= 2^32 bases: 40-bit positions (gene < 2^24)
   int32_t dbg;           // experiments only (MUSC_DEBUG_SCREEN): 1 skip flat phase, 2 skip bucket loads, 4 skip desc writes
 };
 
@@ -518,9 +572,9 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // loads local; nothing downstream needs more than that (k_select / k_emit work per tile in LDS
 // and k_emit orders the tuples by read).
 //
-// Descriptor (16 B): x = read index within the batch, y = global base offset of the
-// placement, z = window | z-flag << 4 | pos_ok << 5 | position in the target << 6 (when it
-// fits 16 bits exactly), w = gene.
+// Descriptor (16 B): x = read index within the batch (24 bits) | bits 32-39 of the placement's
+// global offset << 24, y = its low 32 bits, z = window | z-flag << 4 | pos_ok << 5 | position
+// in the target << 6 (when it fits 16 bits exactly), w = gene.
 // counters: [0] valid windows, [3] candidates (index entries walked), [4] pairs,
 //           [7] the largest number of descriptors any workgroup needed (region size to retry with).
 #define SCR_OWN 2048  // flat items per chunk whose owner is looked up directly
@@ -693,9 +747,13 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
         const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
         const uint32_t pos_ok = left < 65535 ? 1u : 0u;
         const uint32_t slot = atomicAdd(&s_tilecnt, 1u);
-        if (slot < room && !(pp.dbg & 4))
-          desc[base + slot] = make_uint4(tile * TILE + (seg >> 1), ent.y - (uint32_t)q1,
-                                         (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6), ent.x);
+        if (slot < room && !(pp.dbg & 4)) {
+          // global offset of the placement (40 bits in wide mode: the high byte rides in x)
+          const uint64_t gp = (((uint64_t)(pp.wide ? ent.x >> 24 : 0u) << 32) | ent.y) - (uint64_t)q1;
+          desc[base + slot] = make_uint4((tile * TILE + (seg >> 1)) | ((uint32_t)(gp >> 32) << 24), (uint32_t)gp,
+                                         (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6),
+                                         pp.wide ? (ent.x & 0xFFFFFFu) : ent.x);
+        }
       }
       __syncthreads();  // the LDS tables are reused by the next chunk
     }
@@ -758,9 +816,9 @@ __global__ __launch_bounds__(256) void k_confirm(
   // database -- the only operand with reuse -- keeps the Infinity Cache
   const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + idx);
   const uint4 ds = make_uint4(dsv.x, dsv.y, dsv.z, dsv.w);
-  const uint32_t ri = ds.x;
+  const uint32_t ri = ds.x & 0xFFFFFFu;
   const int rw = RW ? RW : rw_rt;
-  const uint64_t gpos = ds.y;
+  const uint64_t gpos = (uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32);
   const uint32_t k = ds.z & 15u, z = (ds.z >> 4) & 1u;
   const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)rw;
   const uint64_t widx = gpos >> 4;
@@ -955,7 +1013,9 @@ __global__ __launch_bounds__(TILE) void k_emit(uint64_t r0, uint32_t n, const ui
       const uint4 ds = cdesc[tb + tj];
       // position in the target: carried in the descriptor unless the target is so long that
       // the entry's 16-bit distance saturated (then one gather of the gene's offset)
-      const uint32_t pos = ((ds.z >> 5) & 1u) ? ((ds.z >> 6) & 0xFFFFu) : (uint32_t)((uint64_t)ds.y - seq_off[ds.w]);
+      const uint32_t pos = ((ds.z >> 5) & 1u)
+                               ? ((ds.z >> 6) & 0xFFFFu)
+                               : (uint32_t)(((uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32)) - seq_off[ds.w]);
       *reinterpret_cast<uint4*>(&hits[base + s_base[rl] + ord]) =
           make_uint4((uint32_t)(r0 + tile * TILE + rl), ds.w, pos, v);
     }
@@ -1044,6 +1104,7 @@ struct musc_ctx {
 
   // index
   int idx_ww = 0, idx_bits = 0, idx_direct = 0;
+  int wide = 0;  // database >= 2^32 bases: 40-bit positions, gene numbers < 2^24
   Bucket* idx_T = nullptr;  // 2^idx_bits buckets
   uint4* idx_E = nullptr;   // overflow entries
   uint64_t idx_n = 0;       // indexed window starts
@@ -1116,6 +1177,8 @@ int ensure(musc_ctx* c, DevBuf<T>& b, uint64_t n, bool keep = false) {
   return 0;
 }
 
+// blocks of b threads covering n elements; a dispatch must stay below 2^32 work-items, callers
+// with potentially larger n use grid-stride kernels instead
 inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 
 // u32 scan of n elements (in may equal out).  tmp must hold scan_tmp_elems(n).
@@ -1144,6 +1207,24 @@ int scan_u32(musc_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, bool in
   int rc = scan_u32(c, sums, sums, nb, false, tmp + ((nb + 8 + 3) & ~3ull));
   if (rc) return rc;
   hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, out, sums, n);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// exclusive u64 scan (in place allowed); tmp must hold scan_tmp_elems(n) u64
+int scan_u64(musc_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_t* tmp) {
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb > 0x7FFFFFFFull) return fail(c, 11, "scan too large");
+  if (nb <= 1) {
+    hipLaunchKernelGGL(k_scan64_block, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, in, out, (uint64_t*)nullptr, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  hipLaunchKernelGGL(k_scan64_block, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, out, tmp, n);
+  HIPCHK(c, hipGetLastError());
+  int rc = scan_u64(c, tmp, tmp, nb, tmp + ((nb + 8 + 3) & ~3ull));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_scan64_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, out, tmp, n);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1336,7 +1417,7 @@ static int db_alloc(musc_ctx* c, const uint64_t* offsets, uint32_t nseq, int on_
     last = offsets[nseq];
   }
   if (first != 0) return fail(c, 2, "offsets[0] must be 0");
-  if (last >= (1ull << 40)) return fail(c, 2, "database larger than 2^40 bases");
+  if (last >= (1ull << 36)) return fail(c, 2, "database larger than 2^36 bases");
   c->nseq = nseq;
   c->nbases = last;
   c->db_words = (last + 15) / 16;
@@ -1412,12 +1493,13 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   HIPCHK(c, hipSetDevice(c->device));
   if (c->idx_ww == ww && c->idx_T) return 0;
   free_index(c);
-  if (c->nbases >= 0xFFFFFFF0ull)
-    return fail(c, 5, "database of %llu bases exceeds the 32-bit positions of this build",
-                (unsigned long long)c->nbases);
+  c->wide = c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE") != nullptr;
+  if (c->wide && c->nseq >= (1u << 24))
+    return fail(c, 5, "a database of 2^32 bases or more may hold at most 2^24 targets (has %u)", c->nseq);
   // Direct addressing (bucket = the 2*ww-bit key itself: exact, and bytewise-sorted reads walk
   // the table front to back) when that table is at most 32x the database and at most 2^30
-  // buckets (64 GiB); otherwise a hashed table with about one bucket per base.
+  // buckets (64 GiB); otherwise a hashed table with about one bucket per base, at most 2^31
+  // buckets (128 GiB; longer lists go to the overflow array).
   int bits, direct = 0;
   const uint64_t floor_bases = std::max<uint64_t>(c->nbases, 1ull << 19);
   if (2 * ww <= 30 && (1ull << (2 * ww)) <= 32 * floor_bases) {
@@ -1425,11 +1507,11 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
     direct = 1;
   } else {
     bits = 10;
-    while (bits < 30 && (1ull << bits) < c->nbases) bits++;
+    while (bits < 31 && (1ull << bits) < c->nbases) bits++;
   }
   if (const char* ov = getenv("MUSC_DEBUG_INDEX_BITS")) {  // experiments only: force a hashed table size
     const int v = atoi(ov);
-    if (v >= 8 && v <= 30) { bits = v; direct = 0; }
+    if (v >= 8 && v <= 31) { bits = v; direct = 0; }
   }
   const uint64_t nb = 1ull << bits;
   hipEvent_t e0, e1;
@@ -1438,32 +1520,32 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   HIPCHK(c, hipEventRecord(e0, c->stream));
   HIPCHK(c, hipMalloc((void**)&c->idx_T, (nb + 1) * sizeof(Bucket)));
   HIPCHK(c, hipMemsetAsync(c->idx_T, 0, (nb + 1) * sizeof(Bucket), c->stream));
-  const unsigned blocks = nblk(c->nbases, 256);
+  const unsigned blocks = (unsigned)std::min<uint64_t>((c->nbases + 255) / 256, 1u << 22);
   if (c->nbases) {
     hipLaunchKernelGGL(k_index<false>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
-                       c->nbases, ww, bits, direct, c->idx_T, (uint4*)nullptr);
+                       c->nbases, ww, bits, direct, c->wide, c->idx_T, (uint4*)nullptr);
     HIPCHK(c, hipGetLastError());
   }
-  // overflow lists: sizes -> offsets
-  uint32_t* tmp = nullptr;
-  HIPCHK(c, hipMalloc((void**)&tmp, (nb + 1 + 16) * 4));
+  // overflow lists: sizes -> offsets (u64: a 10 Gbp database has billions of overflow entries)
+  uint64_t *tmp = nullptr, *stmp = nullptr;
+  HIPCHK(c, hipMalloc((void**)&tmp, (nb + 1 + 16) * 8));
+  HIPCHK(c, hipMalloc((void**)&stmp, scan_tmp_elems(nb + 1) * 8));
   hipLaunchKernelGGL(k_index_ovf_count, dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
   HIPCHK(c, hipGetLastError());
-  int rc = ensure(c, c->scan_tmp, scan_tmp_elems(nb + 1));
+  int rc = scan_u64(c, tmp, tmp, nb + 1, stmp);
   if (rc) return rc;
-  rc = scan_u32(c, tmp, tmp, nb + 1, false, c->scan_tmp.p);
-  if (rc) return rc;
-  uint32_t novf = 0;
-  HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 4, hipMemcpyDeviceToHost, c->stream));
+  uint64_t novf = 0;
+  HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 8, hipMemcpyDeviceToHost, c->stream));
   hipLaunchKernelGGL(k_index_ovf_set, dim3(nblk(nb, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   (void)hipFree(tmp);
+  (void)hipFree(stmp);
   c->idx_novf = novf;
   HIPCHK(c, hipMalloc((void**)&c->idx_E, ((uint64_t)novf + 16) * sizeof(uint4)));
   if (c->nbases) {
     hipLaunchKernelGGL(k_index<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
-                       c->nbases, ww, bits, direct, c->idx_T, c->idx_E);
+                       c->nbases, ww, bits, direct, c->wide, c->idx_T, c->idx_E);
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipEventRecord(e1, c->stream));
@@ -1523,7 +1605,7 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
   HIPCHK(c, hipMalloc((void**)&d_hasx, 4));
   HIPCHK(c, hipMemsetAsync(d_hasx, 0, 4, c->stream));
   void *t1 = nullptr, *t2 = nullptr;
-  if (words / 256 + 1 > 0x7FFFFFFFull) return fail(c, 2, "too many read words");
+  if (words >= (1ull << 32)) return fail(c, 2, "too many read words for one dispatch (reads x record words >= 2^32)");
   if (!packed) {
     const unsigned char* src = ascii;
     if (!on_device && total) {
@@ -1603,6 +1685,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   pp.direct = c->idx_direct;
   pp.mmtol = P->mmtol > 0xFFFF ? 0xFFFF : P->mmtol;
   pp.apply_mmtol = P->apply_mmtol;
+  pp.wide = c->wide;
   if (const char* dv = getenv("MUSC_DEBUG_SCREEN")) pp.dbg = atoi(dv);
   for (int k = 0; k < pp.W; k++) {
     pp.win[k] = P->windows[k];
