@@ -36,6 +36,7 @@ class Workload:
     min_dinuc: int
     max_matches: int = 1000 * 1000
     match_mode: str = "best"
+    revcomp: bool = False  # odd targets are the reverse complements of the even ones (prep_targets -rev)
 
     @property
     def n_unique_reads(self) -> int:
@@ -50,6 +51,10 @@ WORKLOADS = {
     "cfg4shard": Workload("cfg4 shard: 25M reads x 1M targets", 1_000_000, 1000, 25_000_000, 100, (0, 20), 15,
                           0.97, 0, 5),
     "tiny": Workload("tiny: 20k reads x 2k targets", 2_000, 1000, 20_000, 100, (0, 20), 15, 0.97, 0, 5),
+    # per-GPU shard of cfg5: 200M reads / 8 GPUs against 5M targets + reverse complements (10 Gbp),
+    # three windows, MMTol=3 ("exhaustive multi-map")
+    "cfg5shard": Workload("cfg5 shard: 25M reads x 5M targets with -rev (10M sequences)", 10_000_000, 1000,
+                          25_000_000, 100, (0, 20, 40), 15, 0.97, 3, 5, revcomp=True),
 }
 
 _ASCII = (65, 67, 71, 84)  # A C G T
@@ -78,6 +83,13 @@ def gen_targets(wl: Workload, device, seed: int, copy_frac: float = 0.2, copy_su
             sub = torch.rand((e - s, L), device=device, generator=g) < copy_sub
             rnd = torch.randint(0, 4, (e - s, L), dtype=torch.uint8, device=device, generator=g)
             out[s:e] = torch.where(sub, rnd, blk)
+    if wl.revcomp:
+        # cmd/muscato_prep_targets/main.go:48-66, 113-131: sequence 2i+1 = reverse complement of 2i
+        # (codes A0 C1 G2 T3: complement = 3 - code)
+        for s in range(0, T - 1, 2 * chunk):
+            e = min(T - 1, s + 2 * chunk)
+            ev = out[s:e:2]
+            out[s + 1:e + 1:2] = (3 - ev).flip(1)
     lut = _lut(device)
     for s in range(0, T, chunk):
         e = min(T, s + chunk)
