@@ -5,7 +5,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmuscato_hip.so")
+# MUSC_LIB_PATH: another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("MUSC_LIB_PATH") or os.path.join(HERE, "libmuscato_hip.so")
 
 MUSC_MAX_WINDOWS = 16
 

@@ -577,10 +577,36 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // in the target << 6 (when it fits 16 bits exactly), w = gene.
 // counters: [0] valid windows, [3] candidates (index entries walked), [4] pairs,
 //           [7] the largest number of descriptors any workgroup needed (region size to retry with).
-#define SCR_OWN 2048  // flat items per chunk whose owner is looked up directly
+#define SCR_OWN 2048  // overflow items per chunk whose owner is looked up directly
+#define SCR_PROBES (2 * TILE)  // probes per chunk: two windows of every read of the tile
 
+// fit rules + flank filter for one index entry against one probe; true = worth a target gather
+DEV bool screen_entry_ok(const uint4 ent, int q1, int ww, uint32_t rfl, uint32_t lenbud, uint32_t* zflag) {
+  const int q2 = q1 + ww;
+  const int rlen = (int)(lenbud & 0xFFFFu);
+  const int nl = q1 < 8 ? q1 : 8;                                       // bases left of the window
+  const int nr = rlen - q2 < 8 ? (rlen - q2 < 0 ? 0 : rlen - q2) : 8;   // bases right of it
+  const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) | ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
+  const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
+  int lim0 = 100 - ww;            // cmd/muscato_screen/main.go:305 (q1 == 0 there)
+  const int tcap = left + right;  // target length, saturated (exact below 65535)
+  if (lim0 > tcap) lim0 = tcap;
+  const bool fit0 = rlen <= lim0;
+  bool ok = q1 <= left;                  // p = jx - q1 >= 0
+  if (left == 0) ok = ok && fit0;        // window at target position 0: pos-0 path
+  else ok = ok && (rlen - q1 <= right);  // p + len <= T
+  const uint32_t x = rfl ^ ent.w;
+  const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
+  ok = ok && ((uint32_t)__popc(d) <= (lenbud >> 16));
+  *zflag = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
+  return ok;
+}
+
+#ifndef SCR_WAVES
+#define SCR_WAVES 4  // waves per SIMD the register allocator has to leave room for
+#endif
 template <int RW>
-__global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd,
+__global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __restrict__ rd,
                                                  const uint32_t* __restrict__ rdm, uint64_t r0,
                                                  uint32_t n, int rw_rt, PathParams pp,
                                                  const uint16_t* __restrict__ nmiss_tab,
@@ -592,20 +618,27 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
                                                  uint32_t* __restrict__ tbase,
                                                  uint32_t* __restrict__ tcount,
                                                  unsigned long long* __restrict__ counters) {
-  // The entries of a tile's buckets are tested as ONE flat list spread evenly over the 256
-  // threads (a (read, window) with c entries owns c consecutive items): every entry load is
-  // independent and they are issued together.  Walking each read's buckets in its own lane
-  // instead costs a dependent L2 round trip per entry, repeated max-over-lanes times with most
-  // lanes idle -- that chain, not bandwidth, bounded the kernel.  Survivors are appended to the
-  // tile's range of `desc` in arrival order: k_confirm / k_select / k_emit take one workgroup
-  // per tile and never need a read's pairs to be adjacent.
+  // Phase A: a thread per read gates the read's windows and names their buckets.
+  // Phase B: the 64-byte buckets are fetched by quads of lanes (16 bytes each: one wave
+  // instruction brings 16 whole buckets, every line is requested once) and stay in registers:
+  // the lane that holds an inline entry tests it on the spot, so a bucket's count and its
+  // first three entries cost one memory round trip and no LDS staging.  Quads are numbered in
+  // (read, window) order and survivors are appended per wave in lane order, so a tile's
+  // descriptors come out read-major (k_confirm's record loads stay local).
+  // Phase C: entries beyond the third of a bucket live in E; all such entries of the chunk
+  // are tested as ONE flat list spread evenly over the 256 threads (a probe with c overflow
+  // entries owns c consecutive items): every load is independent and they are issued together.
+  // The workgroup keeps little LDS (18 KB) so that eight of them share a CU and one
+  // workgroup's memory round trips hide behind the others' arithmetic.
   __shared__ uint32_t s_wsum[TILE / 64];
-  __shared__ uint4 s_bkt[2 * TILE][4];       // the 64-byte buckets probed by this chunk (2 windows per read)
-  __shared__ uint32_t s_rfl[2 * TILE];       // per probe: the read's own 8+8 flanking bases
-  __shared__ uint32_t s_lenbud[2 * TILE];    // read length | mismatch budget << 16
-  __shared__ uint32_t s_pref[2 * TILE + 1];  // exclusive prefix of the entry counts
-  __shared__ uint16_t s_own[SCR_OWN];        // flat item -> probe
-  __shared__ uint32_t s_tilecnt;             // survivors of the tile so far
+  __shared__ uint32_t s_bb[SCR_PROBES];        // per probe: bucket, WB_NONE when the window takes no part
+  __shared__ uint32_t s_rfl[SCR_PROBES];       // per probe: the read's own 8+8 flanking bases
+  __shared__ uint32_t s_lenbud[SCR_PROBES];    // read length | mismatch budget << 16
+  __shared__ uint32_t s_oc[SCR_PROBES];        // entries of the probe's bucket that live in E
+  __shared__ uint64_t s_ovf[SCR_PROBES];       // where in E
+  __shared__ uint32_t s_pref[SCR_PROBES + 1];  // exclusive prefix of s_oc
+  __shared__ uint16_t s_own[SCR_OWN];          // flat item -> probe
+  __shared__ uint32_t s_tilecnt;               // survivors of the tile so far
   const int rw = RW ? RW : rw_rt;
   const bool has_m = rdm != nullptr;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -651,108 +684,111 @@ __global__ __launch_bounds__(TILE) void k_screen(const uint32_t* __restrict__ rd
     const uint64_t base = region0 + used;
     const uint64_t room = region > used ? region - used : 0;  // descriptors this tile may still write
 
+    // one survivor per set lane of a wave-uniform vote: a wave claims its slots with one LDS
+    // atomic and writes them in lane order
+    auto append = [&](bool ok, const uint4 ent, uint32_t probe, int k, int q1, uint32_t z) {
+      const unsigned long long vote = __ballot(ok);
+      if (vote == 0) return;
+      uint32_t first = 0;
+      if (lane == 0) first = atomicAdd(&s_tilecnt, (uint32_t)__popcll(vote));
+      first = __shfl(first, 0);
+      const uint32_t slot = first + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
+      if (ok && slot < room && !(pp.dbg & 4)) {
+        const uint32_t left = ent.z & 0xFFFFu;
+        const uint32_t pos_ok = left < 65535u ? 1u : 0u;
+        // global offset of the placement (40 bits in wide mode: the high byte rides in x)
+        const uint64_t gp = (((uint64_t)(pp.wide ? ent.x >> 24 : 0u) << 32) | ent.y) - (uint64_t)q1;
+        desc[base + slot] = make_uint4((tile * TILE + (probe >> 1)) | ((uint32_t)(gp >> 32) << 24), (uint32_t)gp,
+                                       (uint32_t)k | (z << 4) | (pos_ok << 5) | ((left - (uint32_t)q1) << 6),
+                                       pp.wide ? (ent.x & 0xFFFFFFu) : ent.x);
+      }
+    };
+
     for (int k0 = 0; k0 < pp.W; k0 += 2) {
       // ---- phase A: which of this read's next two windows take part, and their buckets
-      bool part[2] = {false, false};
-      uint32_t bb[2] = {0, 0};
+      const int q1a = pp.win[k0], q1b = pp.win[k0 + 1 < pp.W ? k0 + 1 : k0];
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int k = k0 + j;
+        uint32_t b = WB_NONE;
         if (active && k < pp.W) {
           // cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185
           const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)pp.ww;
           bool pt = (uint32_t)len >= q2;
           if (pt && pp.min_dinuc > 0) pt = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
           if (pt) {
-            bb[j] = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
+            b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
             s_rfl[2 * threadIdx.x + j] = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
             s_lenbud[2 * threadIdx.x + j] = (uint32_t)len | (budget << 16);
             valid |= 1u << k;
           }
-          part[j] = pt;
-          wb[(uint64_t)i * pp.W + k] = pt ? bb[j] : WB_NONE;
+          wb[(uint64_t)i * pp.W + k] = b;
         }
+        s_bb[2 * threadIdx.x + j] = b;
       }
-      // The buckets themselves: four lanes fetch one 64-byte bucket, 16 bytes each, so one
-      // wave instruction brings 16 whole buckets (16 lines touched instead of 64) and every
-      // line is fetched once -- count and inline entries arrive together and wait in LDS for
-      // the flat phase (the XCD's L2 turns over in microseconds here; re-reading the entries
-      // later from global memory fetched half of the lines from HBM twice).
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
+      __syncthreads();
+      // ---- phase B: buckets by quads; a wave fetches the 128 probes of its own 64 reads
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        uint4 v[4];
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-          const int src = rr * 16 + (lane >> 2);  // the lane of this wave whose probe we fetch
-          const uint32_t b = __shfl(bb[j], src);
-          const int pt = __shfl((int)part[j], src);
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (pt && !(pp.dbg & 2)) v = reinterpret_cast<const uint4*>(T + b)[lane & 3];
-          s_bkt[2 * (wid * 64 + src) + j][lane & 3] = v;
+          const uint32_t b = s_bb[wid * 128 + (4 * h + rr) * 16 + (lane >> 2)];
+          v[rr] = make_uint4(0, 0, 0, 0);
+          if (b != WB_NONE && !(pp.dbg & 2)) v[rr] = reinterpret_cast<const uint4*>(T + b)[lane & 3];
         }
-      }
-      __syncthreads();
-      uint32_t cc[2];
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        cc[j] = s_bkt[2 * threadIdx.x + j][0].x;  // 0 for probes that take no part
-        ncand += cc[j];
-      }
-      uint32_t total = 0;
-      const uint32_t pre = wg_scan(cc[0] + cc[1], &total);
-      s_pref[2 * threadIdx.x] = pre;
-      s_pref[2 * threadIdx.x + 1] = pre + cc[0];
-      if (threadIdx.x == TILE - 1) s_pref[2 * TILE] = total;
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const uint32_t p0 = pre + (j ? cc[0] : 0u);
-        for (uint32_t e = 0; e < cc[j] && p0 + e < SCR_OWN; e++) s_own[p0 + e] = (uint16_t)(2 * threadIdx.x + j);
-      }
-      __syncthreads();
-      // ---- phase B: the chunk's entries as one flat list, in (read, window, entry) order
-      for (uint32_t t = threadIdx.x; t < ((pp.dbg & 1) ? 0u : total); t += TILE) {
-        uint32_t seg;
-        if (t < SCR_OWN) {
-          seg = s_own[t];
-        } else {  // rare: largest seg with s_pref[seg] <= t
-          uint32_t lo = 0, hi = 2 * TILE;
-          while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) / 2;
-            if (s_pref[mid] <= t) lo = mid; else hi = mid;
+        for (int rr = 0; rr < 4; rr++) {
+          const uint32_t probe = wid * 128 + (4 * h + rr) * 16 + (lane >> 2);
+          const uint32_t part = lane & 3;
+          const uint32_t cnt = __shfl(v[rr].x, lane & ~3);  // the header sits in the quad's first lane
+          if (part == 0) {
+            ncand += cnt;
+            s_oc[probe] = cnt > BUCKET_INLINE ? cnt - BUCKET_INLINE : 0u;
+            s_ovf[probe] = (uint64_t)v[rr].z | ((uint64_t)v[rr].w << 32);
           }
-          seg = lo;
+          const int k = k0 + (int)(probe & 1u), q1 = (probe & 1u) ? q1b : q1a;
+          uint32_t z = 0;
+          bool ok = part >= 1 && part - 1 < cnt && !(pp.dbg & 1);
+          if (ok) ok = screen_entry_ok(v[rr], q1, pp.ww, s_rfl[probe], s_lenbud[probe], &z);
+          append(ok, v[rr], probe, k, q1, z);
         }
-        const uint32_t e = t - s_pref[seg];
-        const uint4 hd = s_bkt[seg][0];
-        const uint4 ent = e < BUCKET_INLINE ? s_bkt[seg][1 + e]
-                                            : E[((uint64_t)hd.z | ((uint64_t)hd.w << 32)) + (e - BUCKET_INLINE)];
-        // fit rules + flank filter from the entry alone
-        const int k = k0 + (int)(seg & 1u), q1 = pp.win[k], q2 = q1 + pp.ww;
-        const uint32_t lenbud = s_lenbud[seg];
-        const int rlen = (int)(lenbud & 0xFFFFu);
-        const int nl = q1 < 8 ? q1 : 8;                                       // bases left of the window
-        const int nr = rlen - q2 < 8 ? (rlen - q2 < 0 ? 0 : rlen - q2) : 8;   // bases right of it
-        const uint32_t fmask = (nl ? ((0xFFFFu << (16 - 2 * nl)) & 0xFFFFu) : 0u) | ((nr ? ((1u << (2 * nr)) - 1u) : 0u) << 16);
-        const int left = (int)(ent.z & 0xFFFFu), right = (int)(ent.z >> 16);
-        int lim0 = 100 - pp.ww;         // cmd/muscato_screen/main.go:305 (q1 == 0 there)
-        const int tcap = left + right;  // target length, saturated (exact below 65535)
-        if (lim0 > tcap) lim0 = tcap;
-        const bool fit0 = rlen <= lim0;
-        bool ok = q1 <= left;                  // p = jx - q1 >= 0
-        if (left == 0) ok = ok && fit0;        // window at target position 0: pos-0 path
-        else ok = ok && (rlen - q1 <= right);  // p + len <= T
-        const uint32_t x = s_rfl[seg] ^ ent.w;
-        const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
-        ok = ok && ((uint32_t)__popc(d) <= (lenbud >> 16));
-        if (!ok) continue;
-        const uint32_t z = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
-        const uint32_t pos_ok = left < 65535 ? 1u : 0u;
-        const uint32_t slot = atomicAdd(&s_tilecnt, 1u);
-        if (slot < room && !(pp.dbg & 4)) {
-          // global offset of the placement (40 bits in wide mode: the high byte rides in x)
-          const uint64_t gp = (((uint64_t)(pp.wide ? ent.x >> 24 : 0u) << 32) | ent.y) - (uint64_t)q1;
-          desc[base + slot] = make_uint4((tile * TILE + (seg >> 1)) | ((uint32_t)(gp >> 32) << 24), (uint32_t)gp,
-                                         (uint32_t)k | (z << 4) | (pos_ok << 5) | ((uint32_t)(left - q1) << 6),
-                                         pp.wide ? (ent.x & 0xFFFFFFu) : ent.x);
+      }
+      __syncthreads();
+      // ---- phase C: the chunk's overflow entries as one flat list, in (read, window, entry) order
+      const uint32_t oc0 = s_oc[2 * threadIdx.x], oc1 = s_oc[2 * threadIdx.x + 1];
+      uint32_t total = 0;
+      const uint32_t pre = wg_scan(oc0 + oc1, &total);
+      if (total != 0 && !(pp.dbg & 1)) {  // uniform
+        s_pref[2 * threadIdx.x] = pre;
+        s_pref[2 * threadIdx.x + 1] = pre + oc0;
+        if (threadIdx.x == TILE - 1) s_pref[SCR_PROBES] = total;
+        for (uint32_t e = 0; e < oc0 && pre + e < SCR_OWN; e++) s_own[pre + e] = (uint16_t)(2 * threadIdx.x);
+        for (uint32_t e = 0; e < oc1 && pre + oc0 + e < SCR_OWN; e++) s_own[pre + oc0 + e] = (uint16_t)(2 * threadIdx.x + 1);
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < total; t0 += TILE) {
+          const uint32_t t = t0 + threadIdx.x;
+          bool ok = t < total;
+          uint32_t seg = 0, z = 0;
+          uint4 ent = make_uint4(0, 0, 0, 0);
+          int k = k0, q1 = 0;
+          if (ok) {
+            if (t < SCR_OWN) {
+              seg = s_own[t];
+            } else {  // rare: largest seg with s_pref[seg] <= t
+              uint32_t lo = 0, hi = SCR_PROBES;
+              while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) / 2;
+                if (s_pref[mid] <= t) lo = mid; else hi = mid;
+              }
+              seg = lo;
+            }
+            ent = E[s_ovf[seg] + (t - s_pref[seg])];
+            k = k0 + (int)(seg & 1u);
+            q1 = (seg & 1u) ? q1b : q1a;
+            ok = screen_entry_ok(ent, q1, pp.ww, s_rfl[seg], s_lenbud[seg], &z);
+          }
+          append(ok, ent, seg, k, q1, z);
         }
       }
       __syncthreads();  // the LDS tables are reused by the next chunk
