@@ -602,6 +602,11 @@ DEV bool screen_entry_ok(const uint4 ent, int q1, int ww, uint32_t rfl, uint32_t
   return ok;
 }
 
+DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values derived from x across loop iterations
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 #ifndef SCR_WAVES
 #define SCR_WAVES 4  // waves per SIMD the register allocator has to leave room for
 #endif
@@ -642,7 +647,6 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
   const int rw = RW ? RW : rw_rt;
   const bool has_m = rdm != nullptr;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   unsigned long long nvalid = 0, ncand = 0;
   const uint64_t region = desc_cap / gridDim.x;
   const uint64_t region0 = region * blockIdx.x;
@@ -650,6 +654,8 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
 
   // workgroup exclusive scan helper: returns this thread's exclusive prefix, *total = sum
   auto wg_scan = [&](uint32_t v, uint32_t* total) -> uint32_t {
+    const uint32_t tid = opaque(threadIdx.x);
+    const int lane = tid & 63, wid = tid >> 6;
     uint32_t inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -670,7 +676,8 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
   };
 
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint32_t i = tile * TILE + threadIdx.x;
+    const uint32_t tida = opaque(threadIdx.x);
+    const uint32_t i = tile * TILE + tida;
     const bool active = i < n;
     const uint64_t r = r0 + (active ? i : 0);
     Rec<RW> rec;
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
     const int len = (int)rec.len();
     const uint32_t budget = nmiss_tab[len];
     uint32_t valid = 0;
-    if (threadIdx.x == 0) s_tilecnt = 0;
+    if (tida == 0) s_tilecnt = 0;
     const uint64_t base = region0 + used;
     const uint64_t room = region > used ? region - used : 0;  // descriptors this tile may still write
 
@@ -690,9 +697,10 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       const unsigned long long vote = __ballot(ok);
       if (vote == 0) return;
       uint32_t first = 0;
-      if (lane == 0) first = atomicAdd(&s_tilecnt, (uint32_t)__popcll(vote));
-      first = __shfl(first, 0);
-      const uint32_t slot = first + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull));
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
+      if (below == 0 && ok) first = atomicAdd(&s_tilecnt, (uint32_t)__popcll(vote));  // the first voter
+      first = __builtin_amdgcn_readlane(first, __builtin_ctzll(vote));
+      const uint32_t slot = first + below;
       if (ok && slot < room && !(pp.dbg & 4)) {
         const uint32_t left = ent.z & 0xFFFFu;
         const uint32_t pos_ok = left < 65535u ? 1u : 0u;
@@ -718,18 +726,20 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
           if (pt && pp.min_dinuc > 0) pt = rec_count_dinuc(rec, recm, has_m, q1, pp.ww) >= pp.min_dinuc;
           if (pt) {
             b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
-            s_rfl[2 * threadIdx.x + j] = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
-            s_lenbud[2 * threadIdx.x + j] = (uint32_t)len | (budget << 16);
+            s_rfl[2 * tida + j] = rec_flank_left(rec, q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16);
+            s_lenbud[2 * tida + j] = (uint32_t)len | (budget << 16);
             valid |= 1u << k;
           }
           wb[(uint64_t)i * pp.W + k] = b;
         }
-        s_bb[2 * threadIdx.x + j] = b;
+        s_bb[2 * tida + j] = b;
       }
       __syncthreads();
       // ---- phase B: buckets by quads; a wave fetches the 128 probes of its own 64 reads
 #pragma unroll 1
       for (int h = 0; h < 2; h++) {
+        const uint32_t tidb = opaque(threadIdx.x);
+        const uint32_t lane = tidb & 63, wid = tidb >> 6;
         uint4 v[4];
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
@@ -756,18 +766,19 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       }
       __syncthreads();
       // ---- phase C: the chunk's overflow entries as one flat list, in (read, window, entry) order
-      const uint32_t oc0 = s_oc[2 * threadIdx.x], oc1 = s_oc[2 * threadIdx.x + 1];
+      const uint32_t tidc = opaque(threadIdx.x);
+      const uint32_t oc0 = s_oc[2 * tidc], oc1 = s_oc[2 * tidc + 1];
       uint32_t total = 0;
       const uint32_t pre = wg_scan(oc0 + oc1, &total);
       if (total != 0 && !(pp.dbg & 1)) {  // uniform
-        s_pref[2 * threadIdx.x] = pre;
-        s_pref[2 * threadIdx.x + 1] = pre + oc0;
-        if (threadIdx.x == TILE - 1) s_pref[SCR_PROBES] = total;
-        for (uint32_t e = 0; e < oc0 && pre + e < SCR_OWN; e++) s_own[pre + e] = (uint16_t)(2 * threadIdx.x);
-        for (uint32_t e = 0; e < oc1 && pre + oc0 + e < SCR_OWN; e++) s_own[pre + oc0 + e] = (uint16_t)(2 * threadIdx.x + 1);
+        s_pref[2 * tidc] = pre;
+        s_pref[2 * tidc + 1] = pre + oc0;
+        if (tidc == TILE - 1) s_pref[SCR_PROBES] = total;
+        for (uint32_t e = 0; e < oc0 && pre + e < SCR_OWN; e++) s_own[pre + e] = (uint16_t)(2 * tidc);
+        for (uint32_t e = 0; e < oc1 && pre + oc0 + e < SCR_OWN; e++) s_own[pre + oc0 + e] = (uint16_t)(2 * tidc + 1);
         __syncthreads();
         for (uint32_t t0 = 0; t0 < total; t0 += TILE) {
-          const uint32_t t = t0 + threadIdx.x;
+          const uint32_t t = t0 + tidc;
           bool ok = t < total;
           uint32_t seg = 0, z = 0;
           uint4 ent = make_uint4(0, 0, 0, 0);
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
     const uint32_t total = s_tilecnt;
     const bool fits = total <= room;  // else: the host grows desc and repeats the batch
     used += total;
-    if (threadIdx.x == 0) {
+    if (tida == 0) {
       tbase[tile] = (uint32_t)base;
       tcount[tile] = fits ? total : 0u;
     }
@@ -828,30 +839,19 @@ struct __attribute__((packed, aligned(4))) u32x4_u {
   uint32_t x, y, z, w;
 };
 
-// k_confirm -- one lane per candidate pair.  Loads the 2-bit read record (aligned, neighbouring
-// lanes mostly share it) and the target span at an arbitrary base offset (dword-aligned
-// 16-byte gathers + funnel shift), XOR + popcount = cdiff over the whole read
+// confirm_pair -- cdiff for one candidate pair.  Loads the 2-bit read record (aligned,
+// neighbouring lanes mostly share it) and the target span at an arbitrary base offset
+// (dword-aligned 16-byte gathers + funnel shift), XOR + popcount = cdiff over the whole read
 // (cmd/muscato_confirm/main.go:151-159, 205-211; X==X through the mask plane), then decides
 // whether THIS window is the first window of the read that the reference would have emitted
 // the tuple through (exact window key + fit), which makes the union over windows a set
-// without a sort.  RW = record words (compile time) or 0 = runtime stride.  One workgroup per
-// tile of k_screen: its pairs are desc[tbase[tile] .. +tcount[tile]).
+// without a sort.  RW = record words (compile time) or 0 = runtime stride.
+// Returns the pair's result word (NX_REJECT, or nmiss | NX_DUP | window << 20 | slot << 24).
 template <int RW, bool MASK>
-__global__ __launch_bounds__(256) void k_confirm(
-    const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
-    const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, int rw_rt,
-    PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
-    const uint32_t* __restrict__ rvalid, uint32_t* __restrict__ p_nx,
-    const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ tcount) {
-  const uint32_t tile = blockIdx.x;
-  const uint32_t tn = tcount[tile];
-  const uint64_t tb = tbase[tile];
-  for (uint32_t tj = threadIdx.x; tj < tn; tj += blockDim.x) {
-  const uint64_t idx = tb + tj;
-  // descriptors, read records and results stream through once: non-temporal, so that the
-  // database -- the only operand with reuse -- keeps the Infinity Cache
-  const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + idx);
-  const uint4 ds = make_uint4(dsv.x, dsv.y, dsv.z, dsv.w);
+DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
+                          const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0,
+                          int rw_rt, const PathParams& pp, const uint16_t* __restrict__ nmiss_tab,
+                          const uint32_t* __restrict__ rvalid) {
   const uint32_t ri = ds.x & 0xFFFFFFu;
   const int rw = RW ? RW : rw_rt;
   const uint64_t gpos = (uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32);
@@ -864,7 +864,9 @@ __global__ __launch_bounds__(256) void k_confirm(
 
   uint32_t nx = 0, len;
   if constexpr (RW != 0) {
-    // ---- static stride: whole record and span in registers, 16-byte loads
+    // ---- static stride: whole record and span in registers, 16-byte loads.  Read records
+    // stream through once: non-temporal, so that the database -- the only operand with reuse --
+    // keeps the Infinity Cache
     uint32_t r[RW], t[RW], rm[RW], tm[RW];
 #pragma unroll
     for (int q = 0; q < RW / 4; q++) {
@@ -920,22 +922,26 @@ __global__ __launch_bounds__(256) void k_confirm(
   // window-key block's MaxMatches); it is reported here only if k is the first such window.
   const bool own = ((exact >> k) & 1u) && (nx <= nmiss_tab[len]);
   const uint32_t kmin = (uint32_t)(__ffs(exact) - 1);
-  const uint32_t code = !own ? NX_REJECT : ((kmin == k ? nx : (nx | NX_DUP)) | (k << 20) | ((ri & (TILE - 1)) << 24));
-  __builtin_nontemporal_store(code, &p_nx[idx]);
-  }
+  return !own ? NX_REJECT : ((kmin == k ? nx : (nx | NX_DUP)) | (k << 20) | ((ri & (TILE - 1)) << 24));
 }
 
-// (sketch size)
-#define BLOCK_LDS_BITS 11
+#define BLOCK_LDS_BITS 11  // sketch size
+#define CODE_CAP 2048      // result words of a tile kept in LDS; a larger tile spills the rest to p_nx
 
-// k_select -- per-read best + MMTol (cmd/muscato_combine_windows/main.go:36-60) and the
-// MaxMatches block accounting, one workgroup per tile (persistent over tiles).  A tile's pairs
-// lie in one range of p_nx in any order; per-read state lives in LDS.
-//   pass 1: best[read] = min nmiss over its reported pairs; wcnt[read][window] = pairs that
-//           window's confirm accepts (its share of the (window,key) block, which
-//           cmd/muscato_confirm/main.go:233-242, 424-448 truncate at MaxMatches)
-//   pass 2: hcnt[read] = pairs with nmiss <= best + MMTol (all accepted pairs when
-//           apply_mmtol == 0), hthr[read] = that threshold
+// k_confirm -- muscato_confirm for one tile of k_screen per workgroup iteration, followed in
+// the same workgroup by the per-read best + MMTol filter
+// (cmd/muscato_combine_windows/main.go:36-60) and the MaxMatches block accounting: a tile's
+// pairs are desc[tbase[tile] .. +tcount[tile]) in any order, every per-read quantity lives in
+// LDS and the result words never travel through HBM (tiles of more than CODE_CAP pairs spill).
+//   pass 1: one lane per pair: cdiff; best[read] = min nmiss over its reported pairs;
+//           wcnt[read][window] = pairs that window's confirm accepts (its share of the
+//           (window,key) block, which cmd/muscato_confirm/main.go:233-242, 424-448 truncate
+//           at MaxMatches)
+//   pass 2: cnt[read] = pairs with nmiss <= best + MMTol (all accepted pairs when
+//           apply_mmtol == 0); scan over the tile's reads
+//   pass 3: the surviving tuples go to stage[tbase[tile] + ...], reads in order, a read's
+//           tuples contiguous (arrival order within one read); tcount2[tile] = how many.
+//           k_compact then closes the gaps between tiles.
 // block_mode 0: no MaxMatches accounting.
 // block_mode 1: screening -- each workgroup keeps a count-min sketch of (window, key) -> accepted
 //   pairs in LDS across all its tiles; if no sketch cell of any workgroup of any launch reaches
@@ -943,21 +949,26 @@ __global__ __launch_bounds__(256) void k_confirm(
 //   hold more than MaxMatches pairs (cells only over-estimate).  Otherwise counters[6] is raised
 //   and the host repeats the pass in mode 2.
 // block_mode 2: exact -- one global atomic per (read, window) into a 2^22-cell table.
-__global__ __launch_bounds__(TILE) void k_select(uint32_t n, PathParams pp,
-                                                 const uint32_t* __restrict__ tbase,
-                                                 const uint32_t* __restrict__ tcount,
-                                                 const uint32_t* __restrict__ p_nx,
-                                                 const uint32_t* __restrict__ wb, int block_mode,
-                                                 uint32_t block_thr, uint32_t* __restrict__ block_table,
-                                                 uint32_t* __restrict__ hcnt, uint32_t* __restrict__ hthr,
-                                                 unsigned long long* __restrict__ counters) {
-  __shared__ uint32_t s_best[TILE], s_cnt[TILE];
-  __shared__ uint32_t s_wcnt[TILE * MUSC_MAX_WINDOWS];
+template <int RW, bool MASK>
+__global__ __launch_bounds__(TILE) void k_confirm(
+    const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
+    const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, uint32_t n, int rw_rt,
+    PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
+    const uint32_t* __restrict__ rvalid, uint32_t* __restrict__ p_nx,
+    const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ tcount,
+    const uint32_t* __restrict__ wb, int block_mode, uint32_t block_thr, uint32_t* __restrict__ block_table,
+    const uint64_t* __restrict__ seq_off, uint4* __restrict__ stage, uint32_t* __restrict__ tcount2,
+    unsigned long long* __restrict__ counters) {
+  extern __shared__ uint32_t s_wcnt[];  // TILE * W counters when block_mode != 0
+  __shared__ uint32_t s_best[TILE], s_cnt[TILE], s_base[TILE];
+  __shared__ uint32_t s_code[CODE_CAP];
   __shared__ uint32_t s_sketch[1 << BLOCK_LDS_BITS];
+  __shared__ uint32_t s_wsum[TILE / 64];
   const uint32_t ntiles = (n + TILE - 1) / TILE;
-  if (block_mode == 1) {
-    for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += blockDim.x) s_sketch[t] = 0;
-  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (block_mode == 1)
+    for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += TILE) s_sketch[t] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) tcount2[ntiles] = 0;
   unsigned long long acc = 0;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();  // the previous tile is done with the LDS state
@@ -968,8 +979,13 @@ __global__ __launch_bounds__(TILE) void k_select(uint32_t n, PathParams pp,
     __syncthreads();
     const uint32_t tn = tcount[tile];
     const uint64_t tb = tbase[tile];
+    // ---- pass 1
     for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
-      const uint32_t w = p_nx[tb + tj];
+      // descriptors stream through once: non-temporal
+      const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + tb + tj);
+      const uint32_t w = confirm_pair<RW, MASK>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, r0,
+                                                rw_rt, pp, nmiss_tab, rvalid);
+      if (tj < CODE_CAP) s_code[tj] = w; else p_nx[tb + tj] = w;
       if (w == NX_REJECT) continue;
       const uint32_t rl = w >> 24;
       if (block_mode) atomicAdd(&s_wcnt[rl * pp.W + ((w >> 20) & 15u)], 1u);
@@ -978,8 +994,9 @@ __global__ __launch_bounds__(TILE) void k_select(uint32_t n, PathParams pp,
       acc++;
     }
     __syncthreads();
+    // ---- pass 2
     for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
-      const uint32_t w = p_nx[tb + tj];
+      const uint32_t w = tj < CODE_CAP ? s_code[tj] : p_nx[tb + tj];
       if (w == NX_REJECT || (w & NX_DUP)) continue;
       const uint32_t rl = w >> 24;
       const uint32_t thr = pp.apply_mmtol ? s_best[rl] + (uint32_t)pp.mmtol : 0xFFFFu;
@@ -996,65 +1013,66 @@ __global__ __launch_bounds__(TILE) void k_select(uint32_t n, PathParams pp,
       }
     }
     __syncthreads();
-    const uint32_t i = tile * TILE + threadIdx.x;
-    if (i < n) {
-      const uint32_t c = s_cnt[threadIdx.x];
-      uint32_t thr = pp.apply_mmtol ? s_best[threadIdx.x] + (uint32_t)pp.mmtol : 0xFFFFu;
-      if (thr > 0xFFFFu) thr = 0xFFFFu;
-      hcnt[i] = c;
-      hthr[i] = c ? thr : 0xFFFFFFFFu;
+    // ---- scan of the per-read counts
+    const uint32_t c = s_cnt[threadIdx.x];
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
     }
-  }
-  block_add_u64(acc, &counters[1]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) hcnt[n] = 0;
-  if (block_mode == 1) {
+    if (lane == 63) s_wsum[wid] = inc;
     __syncthreads();
-    uint32_t hot = 0;
-    for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += blockDim.x) hot |= s_sketch[t] >= block_thr;
-    if (__any(hot) && (threadIdx.x & 63) == 0) atomicOr(&counters[6], 1ull);
-  }
-}
-
-// k_emit -- one workgroup per tile: write the tuples of each read at
-// hits[counters[2] + hbase[read] ...] (hbase = scan of hcnt).  A read's tuples are contiguous
-// and reads are in order; the order of the tuples within one read is arrival order.
-__global__ __launch_bounds__(TILE) void k_emit(uint64_t r0, uint32_t n, const uint32_t* __restrict__ tbase,
-                                               const uint32_t* __restrict__ tcount,
-                                               const uint32_t* __restrict__ hbase,
-                                               const uint32_t* __restrict__ hthr,
-                                               const uint4* __restrict__ cdesc,
-                                               const uint32_t* __restrict__ p_nx,
-                                               const uint64_t* __restrict__ seq_off,
-                                               musc_hit* __restrict__ hits,
-                                               const unsigned long long* __restrict__ counters) {
-  __shared__ uint32_t s_ord[TILE], s_thr[TILE], s_base[TILE];
-  const unsigned long long base = counters[2];
-  const uint32_t ntiles = (n + TILE - 1) / TILE;
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < TILE / 64; q++) {
+      if (q < wid) woff += s_wsum[q];
+      total += s_wsum[q];
+    }
+    s_base[threadIdx.x] = woff + inc - c;
+    s_cnt[threadIdx.x] = 0;  // now the arrival counter of the read
+    if (threadIdx.x == 0) tcount2[tile] = total;
     __syncthreads();
-    const uint32_t i = tile * TILE + threadIdx.x;
-    s_ord[threadIdx.x] = 0;
-    s_thr[threadIdx.x] = i < n ? hthr[i] : 0xFFFFFFFFu;
-    s_base[threadIdx.x] = i < n ? hbase[i] : 0u;
-    __syncthreads();
-    const uint32_t tn = tcount[tile];
-    const uint64_t tb = tbase[tile];
+    // ---- pass 3
+    if (total == 0) continue;
     for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
-      const uint32_t w = p_nx[tb + tj];
+      const uint32_t w = tj < CODE_CAP ? s_code[tj] : p_nx[tb + tj];
       if (w == NX_REJECT || (w & NX_DUP)) continue;
       const uint32_t rl = w >> 24, v = w & 0xFFFFu;
-      const uint32_t thr = s_thr[rl];
-      if (thr == 0xFFFFFFFFu || v > thr) continue;
-      const uint32_t ord = atomicAdd(&s_ord[rl], 1u);
+      const uint32_t thr = pp.apply_mmtol ? s_best[rl] + (uint32_t)pp.mmtol : 0xFFFFu;
+      if (v > thr) continue;
+      const uint32_t ord = atomicAdd(&s_cnt[rl], 1u);
       const uint4 ds = cdesc[tb + tj];
       // position in the target: carried in the descriptor unless the target is so long that
       // the entry's 16-bit distance saturated (then one gather of the gene's offset)
       const uint32_t pos = ((ds.z >> 5) & 1u)
                                ? ((ds.z >> 6) & 0xFFFFu)
                                : (uint32_t)(((uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32)) - seq_off[ds.w]);
-      *reinterpret_cast<uint4*>(&hits[base + s_base[rl] + ord]) =
-          make_uint4((uint32_t)(r0 + tile * TILE + rl), ds.w, pos, v);
+      stage[tb + s_base[rl] + ord] = make_uint4((uint32_t)(r0 + tile * TILE + rl), ds.w, pos, v);
     }
+  }
+  block_add_u64(acc, &counters[1]);
+  if (block_mode == 1) {
+    __syncthreads();
+    uint32_t hot = 0;
+    for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += TILE) hot |= s_sketch[t] >= block_thr;
+    if (__any(hot) && (threadIdx.x & 63) == 0) atomicOr(&counters[6], 1ull);
+  }
+}
+
+// k_compact -- hits[counters[2] + tpre[tile] ...] = the tile's staged tuples (tpre = scan of
+// tcount2): plain 16-byte copies, a tile's run is contiguous on both sides.
+__global__ __launch_bounds__(256) void k_compact(uint32_t ntiles, const uint32_t* __restrict__ tbase,
+                                                 const uint32_t* __restrict__ tcount2,
+                                                 const uint32_t* __restrict__ tpre,
+                                                 const uint4* __restrict__ stage, uint4* __restrict__ hits,
+                                                 const unsigned long long* __restrict__ counters) {
+  const unsigned long long base = counters[2];
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t m = tcount2[tile];
+    const uint4* __restrict__ src = stage + tbase[tile];
+    uint4* __restrict__ dst = hits + base + tpre[tile];
+    for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) dst[j] = src[j];
   }
 }
 
@@ -1089,9 +1107,9 @@ __global__ __launch_bounds__(256) void k_hot_probes(const uint32_t* __restrict__
   }
 }
 
-// counters[2] (hits so far) += hbase[n] (hits of this batch)
-__global__ void k_advance(const uint32_t* __restrict__ hbase, uint32_t n, unsigned long long* counters) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) counters[2] += hbase[n];
+// counters[2] (hits so far) += tpre[ntiles] (hits of this batch)
+__global__ void k_advance(const uint32_t* __restrict__ tpre, uint32_t ntiles, unsigned long long* counters) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) counters[2] += tpre[ntiles];
 }
 
 // number of block counters above MaxMatches (hash collisions only inflate counters, so 0 is
@@ -1154,12 +1172,14 @@ struct musc_ctx {
   uint32_t max_len = 0;
 
   // per-batch work buffers
-  DevBuf<uint32_t> wb, rvalid, tbase, tcount, scan_tmp, hcnt, hbase, hthr;
-  DevBuf<uint4> cdesc;
+  DevBuf<uint32_t> wb, rvalid, tbase, tcount, scan_tmp, tcount2, tpre;
+  DevBuf<uint4> cdesc, stage;
   DevBuf<uint32_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
   DevBuf<uint32_t> block_table;
   bool force_exact_blocks = false;
+  int cur_block_mode = 0;          // of the pass in flight
+  uint32_t cur_block_thr = 0;
   PathParams last_pp;          // of the last musc_match_device
   uint32_t last_max_matches = 0;
   bool last_exact_blocks = false;  // block_table holds exact counters of that pass
@@ -1348,13 +1368,19 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
                        n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap, c->rvalid.p,
                        c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
   } else {
-    const dim3 grid(nblk(n, TILE));  // one workgroup per k_screen tile
+    // persistent over tiles; the MaxMatches screening threshold assumes at most MAX_GRID workgroups
+    const dim3 grid(std::min(nblk(n, TILE), MAX_GRID));
+    const size_t lds = c->cur_block_mode ? (size_t)TILE * pp.W * 4 : 0;
     if (mask)
-      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p);
+      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, lds, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p,
+                         c->wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
+                         c->tcount2.p, c->counters);
     else
-      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, 0, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p);
+      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, lds, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
+                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p,
+                         c->wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
+                         c->tcount2.p, c->counters);
   }
 }
 
@@ -1415,7 +1441,7 @@ void musc_destroy(musc_ctx* c) {
   free_db(c);
   free_reads(c);
   c->wb.release(); c->tbase.release();
-  c->scan_tmp.release(); c->hcnt.release(); c->hbase.release(); c->hthr.release();
+  c->scan_tmp.release(); c->tcount2.release(); c->tpre.release(); c->stage.release();
   c->rvalid.release(); c->tcount.release(); c->cdesc.release(); c->p_nx.release();
   c->nmiss_tab.release();
   c->block_table.release();
@@ -1755,6 +1781,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   const uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * MAX_GRID), 0x7FFFFFFFull);
   int block_mode = P->skip_block_check ? 0 : (c->force_exact_blocks || block_thr < 2 ? 2 : 1);
   const bool check_blocks = block_mode != 0;
+  c->cur_block_mode = block_mode;
+  c->cur_block_thr = block_thr;
   if (block_mode == 2) {
     if ((rc = ensure(c, c->block_table, 1ull << BLOCK_TABLE_BITS))) return rc;
     HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
@@ -1793,10 +1821,9 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if ((rc = ensure(c, c->rvalid, (uint64_t)n + 1))) return rc;
     if ((rc = ensure(c, c->tbase, (uint64_t)ntiles + 1))) return rc;
     if ((rc = ensure(c, c->tcount, (uint64_t)ntiles + 1))) return rc;
-    if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)n + 1)))) return rc;
-    if ((rc = ensure(c, c->hcnt, (uint64_t)n + 1))) return rc;
-    if ((rc = ensure(c, c->hbase, (uint64_t)n + 1))) return rc;
-    if ((rc = ensure(c, c->hthr, (uint64_t)n + 1))) return rc;
+    if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)ntiles + 1)))) return rc;
+    if ((rc = ensure(c, c->tcount2, (uint64_t)ntiles + 1))) return rc;
+    if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
     if ((rc = ensure(c, c->cdesc, std::max<uint64_t>(4ull * n, 1024)))) return rc;
 
     tm.begin(0);
@@ -1827,6 +1854,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     n_cand += c->h_pinned[3];
     n_pairs += c->h_pinned[4];
     if ((rc = ensure(c, c->p_nx, c->cdesc.cap))) return rc;
+    if ((rc = ensure(c, c->stage, c->cdesc.cap))) return rc;
     if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
 
     if (total) {
@@ -1839,17 +1867,14 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       c->stats.confirm_launches++;
 
       tm.begin(4);
-      hipLaunchKernelGGL(k_select, sg, dim3(TILE), 0, c->stream, n, pp, c->tbase.p, c->tcount.p, c->p_nx.p, c->wb.p,
-                         block_mode, block_thr, c->block_table.p, c->hcnt.p, c->hthr.p, c->counters);
-      HIPCHK(c, hipGetLastError());
       tm.begin(1);
-      rc = scan_u32(c, c->hcnt.p, c->hbase.p, (uint64_t)n + 1, false, c->scan_tmp.p);
+      rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p);
       if (rc) return rc;
       tm.end(1);
-      hipLaunchKernelGGL(k_emit, sg, dim3(TILE), 0, c->stream, r0, n, c->tbase.p, c->tcount.p, c->hbase.p, c->hthr.p,
-                         c->cdesc.p, c->p_nx.p, c->seq_off, c->hits.p, c->counters);
+      hipLaunchKernelGGL(k_compact, sg, dim3(256), 0, c->stream, ntiles, c->tbase.p, c->tcount2.p, c->tpre.p,
+                         c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->counters);
       HIPCHK(c, hipGetLastError());
-      hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->hbase.p, n, c->counters);
+      hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->tpre.p, ntiles, c->counters);
       HIPCHK(c, hipGetLastError());
       tm.end(4);
     }
