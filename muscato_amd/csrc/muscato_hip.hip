@@ -439,7 +439,7 @@ struct PathParams {
   int32_t apply_mmtol;
   uint32_t q1zero_mask;  // windows whose start is 0 (the pos-0 path of processSeq)
   int32_t wide;          // database >= 2^32 bases: 40-bit positions (gene < 2^24)
-  int32_t dbg;           // experiments only (MUSC_DEBUG_SCREEN): 1 skip flat phase, 2 skip bucket loads, 4 skip desc writes
+  int32_t dbg;           // experiments only (MUSC_DEBUG_SCREEN): 1 skip entry tests, 2 skip bucket loads, 4 skip desc writes, 8 no two-window descriptors
 };
 
 // A read record: RW u32 words, bases (2 bits each) in words 0..RW-2, length in word RW-1.
@@ -543,11 +543,13 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
   return __popc(seen25);
 }
 
-// per-pair result word: bits 0-15 mismatch count, bit 16 NX_DUP, bits 20-23 window,
-// bits 24-31 the read's slot within its tile
+// per-pair result word: bits 0-15 mismatch count, bit 16 NX_DUP, bits 17-18 which of the
+// descriptor's windows accept, bits 20-23 window, bits 24-31 the read's slot within its tile
 #define NX_REJECT 0xFFFFFFFFu
 #define NX_DUP 0x10000u  // accepted through this window, but an earlier window reports the tuple
-#define NX_MASK 0x1FFFFu
+#define NX_ACC1 0x20000u  // the descriptor's second window (k + 1) accepts the pair
+#define NX_ACC0 0x40000u  // the descriptor's window k accepts the pair
+#define DESC_TWO (1u << 22)  // descriptor z: windows k and k + 1 both found this placement
 #define BLOCK_TABLE_BITS 22
 #define WB_NONE 0xFFFFFFFFu
 
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
 
     // one survivor per set lane of a wave-uniform vote: a wave claims its slots with one LDS
     // atomic and writes them in lane order
-    auto append = [&](bool ok, const uint4 ent, uint32_t probe, int k, int q1, uint32_t z) {
+    auto append = [&](bool ok, const uint4 ent, uint32_t probe, int k, int q1, uint32_t z, bool two) {
       const unsigned long long vote = __ballot(ok);
       if (vote == 0) return;
       uint32_t first = 0;
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
         // global offset of the placement (40 bits in wide mode: the high byte rides in x)
         const uint64_t gp = (((uint64_t)(pp.wide ? ent.x >> 24 : 0u) << 32) | ent.y) - (uint64_t)q1;
         desc[base + slot] = make_uint4((tile * TILE + (probe >> 1)) | ((uint32_t)(gp >> 32) << 24), (uint32_t)gp,
-                                       (uint32_t)k | (z << 4) | (pos_ok << 5) | ((left - (uint32_t)q1) << 6),
+                                       (uint32_t)k | (z << 4) | (pos_ok << 5) | ((left - (uint32_t)q1) << 6) | (two ? DESC_TWO : 0u),
                                        pp.wide ? (ent.x & 0xFFFFFFu) : ent.x);
       }
     };
@@ -761,7 +763,31 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
           uint32_t z = 0;
           bool ok = part >= 1 && part - 1 < cnt && !(pp.dbg & 1);
           if (ok) ok = screen_entry_ok(v[rr], q1, pp.ww, s_rfl[probe], s_lenbud[probe], &z);
-          append(ok, v[rr], probe, k, q1, z);
+          // The read's two windows sit in neighbouring quads.  When both hold a surviving entry
+          // for the same placement, one descriptor stands for both (k_confirm compares the
+          // pair once and credits both windows); the second window's lane drops its own.
+          // Every lane executes every cross-lane move: no short-circuit evaluation here.
+          const uint32_t gp = v[rr].y - (uint32_t)q1;
+          const uint32_t gx = ok ? v[rr].x : 0xFFFFFFFFu;  // no target has this number
+          const bool odd = (probe & 1u) != 0;
+          const uint32_t nx0 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)gx, 0x114, 0xF, 0xF, false);  // row_shr:4
+          const uint32_t nx1 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)gx, 0x104, 0xF, 0xF, false);  // row_shl:4
+          const uint32_t ng0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gp, 0x114, 0xF, 0xF, false);
+          const uint32_t ng1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gp, 0x104, 0xF, 0xF, false);
+          const uint32_t px = odd ? nx0 : nx1, pg = odd ? ng0 : ng1;  // the partner quad, same part
+          uint32_t same = (uint32_t)(px == gx) & (uint32_t)(pg == gp);
+#define MUSC_QROT(CTRL)                                                                            \
+          {                                                                                        \
+            const uint32_t qx = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, CTRL, 0xF, 0xF, true); \
+            const uint32_t qg = (uint32_t)__builtin_amdgcn_mov_dpp((int)pg, CTRL, 0xF, 0xF, true); \
+            same |= (uint32_t)(qx == gx) & (uint32_t)(qg == gp);                                   \
+          }
+          MUSC_QROT(0x39) MUSC_QROT(0x4E) MUSC_QROT(0x93)  // the partner quad's other three parts
+#undef MUSC_QROT
+          if (!ok || (pp.dbg & 8)) same = 0;
+          const bool two = same && !odd;
+          if (same && odd) ok = false;
+          append(ok, v[rr], probe, k, q1, z, two);
         }
       }
       __syncthreads();
@@ -799,7 +825,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
             q1 = (seg & 1u) ? q1b : q1a;
             ok = screen_entry_ok(ent, q1, pp.ww, s_rfl[seg], s_lenbud[seg], &z);
           }
-          append(ok, ent, seg, k, q1, z);
+          append(ok, ent, seg, k, q1, z, false);
         }
       }
       __syncthreads();  // the LDS tables are reused by the next chunk
@@ -918,11 +944,16 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
         if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
     }
   }
-  // own: the reference's confirm for window k accepts this pair (it counts towards that
-  // window-key block's MaxMatches); it is reported here only if k is the first such window.
-  const bool own = ((exact >> k) & 1u) && (nx <= nmiss_tab[len]);
+  // The reference's confirm for window k (and for k + 1 when the descriptor stands for both)
+  // accepts this pair -- it counts towards that window-key block's MaxMatches; the tuple is
+  // reported here only if the first window that accepts it is one of this descriptor's.
+  const bool within = nx <= nmiss_tab[len];
+  const bool a0 = within && ((exact >> k) & 1u);
+  const bool a1 = within && (ds.z & DESC_TWO) && ((exact >> (k + 1)) & 1u);
+  if (!(a0 || a1)) return NX_REJECT;
   const uint32_t kmin = (uint32_t)(__ffs(exact) - 1);
-  return !own ? NX_REJECT : ((kmin == k ? nx : (nx | NX_DUP)) | (k << 20) | ((ri & (TILE - 1)) << 24));
+  const bool first = (a0 && kmin == k) || (a1 && kmin == k + 1);
+  return (first ? nx : (nx | NX_DUP)) | (a0 ? NX_ACC0 : 0u) | (a1 ? NX_ACC1 : 0u) | (k << 20) | ((ri & (TILE - 1)) << 24);
 }
 
 #define BLOCK_LDS_BITS 11  // sketch size
@@ -988,7 +1019,11 @@ __global__ __launch_bounds__(TILE) void k_confirm(
       if (tj < CODE_CAP) s_code[tj] = w; else p_nx[tb + tj] = w;
       if (w == NX_REJECT) continue;
       const uint32_t rl = w >> 24;
-      if (block_mode) atomicAdd(&s_wcnt[rl * pp.W + ((w >> 20) & 15u)], 1u);
+      if (block_mode) {
+        const uint32_t k = (w >> 20) & 15u;
+        if (w & NX_ACC0) atomicAdd(&s_wcnt[rl * pp.W + k], 1u);
+        if (w & NX_ACC1) atomicAdd(&s_wcnt[rl * pp.W + k + 1], 1u);
+      }
       if (w & NX_DUP) continue;
       atomicMin(&s_best[rl], w & 0xFFFFu);
       acc++;
