@@ -739,7 +739,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       __syncthreads();
       // ---- phase B: buckets by quads; a wave fetches the 128 probes of its own 64 reads
 #pragma unroll 1
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < ((pp.dbg & 256) ? 0 : 2); h++) {
         const uint32_t tidb = opaque(threadIdx.x);
         const uint32_t lane = tidb & 63, wid = tidb >> 6;
         uint4 v[4];
@@ -793,6 +793,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       __syncthreads();
       // ---- phase C: the chunk's overflow entries as one flat list, in (read, window, entry) order
       const uint32_t tidc = opaque(threadIdx.x);
+      if (pp.dbg & 256) continue;
       const uint32_t oc0 = s_oc[2 * tidc], oc1 = s_oc[2 * tidc + 1];
       uint32_t total = 0;
       const uint32_t pre = wg_scan(oc0 + oc1, &total);
@@ -957,7 +958,7 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
 }
 
 #define BLOCK_LDS_BITS 11  // sketch size
-#define CODE_CAP 2048      // result words of a tile kept in LDS; a larger tile spills the rest to p_nx
+#define CODE_CAP 1024      // result words beyond a lane's first kept in LDS; a larger tile spills the rest to p_nx
 
 // k_confirm -- muscato_confirm for one tile of k_screen per workgroup iteration, followed in
 // the same workgroup by the per-read best + MMTol filter
@@ -1010,33 +1011,48 @@ __global__ __launch_bounds__(TILE) void k_confirm(
     __syncthreads();
     const uint32_t tn = tcount[tile];
     const uint64_t tb = tbase[tile];
-    // ---- pass 1
-    for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
-      // descriptors stream through once: non-temporal
-      const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + tb + tj);
-      const uint32_t w = confirm_pair<RW, MASK>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, r0,
-                                                rw_rt, pp, nmiss_tab, rvalid);
-      if (tj < CODE_CAP) s_code[tj] = w; else p_nx[tb + tj] = w;
-      if (w == NX_REJECT) continue;
+    // ---- pass 1.  The lane's first pair (five tiles in six have no second) stays in
+    // registers through all three passes; later ones park their result word in LDS.
+    auto tally = [&](uint32_t w) {
+      if (w == NX_REJECT) return;
       const uint32_t rl = w >> 24;
       if (block_mode) {
         const uint32_t k = (w >> 20) & 15u;
         if (w & NX_ACC0) atomicAdd(&s_wcnt[rl * pp.W + k], 1u);
         if (w & NX_ACC1) atomicAdd(&s_wcnt[rl * pp.W + k + 1], 1u);
       }
-      if (w & NX_DUP) continue;
+      if (w & NX_DUP) return;
       atomicMin(&s_best[rl], w & 0xFFFFu);
       acc++;
+    };
+    auto confirm_at = [&](uint32_t tj, uint32_t* gene, uint32_t* zword) -> uint32_t {
+      // descriptors stream through once: non-temporal
+      const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + tb + tj);
+      *gene = dsv.w;
+      *zword = dsv.z;
+      return confirm_pair<RW, MASK>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, r0, rw_rt, pp,
+                                    nmiss_tab, rvalid);
+    };
+    uint32_t w0 = NX_REJECT, gene0 = 0, z0 = 0;
+    if (threadIdx.x < tn) w0 = confirm_at(threadIdx.x, &gene0, &z0);
+    tally(w0);
+    for (uint32_t tj = threadIdx.x + TILE; tj < tn; tj += TILE) {
+      uint32_t g, z;
+      const uint32_t w = confirm_at(tj, &g, &z);
+      if (tj - TILE < CODE_CAP) s_code[tj - TILE] = w; else p_nx[tb + tj] = w;
+      tally(w);
     }
     __syncthreads();
     // ---- pass 2
-    for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
-      const uint32_t w = tj < CODE_CAP ? s_code[tj] : p_nx[tb + tj];
-      if (w == NX_REJECT || (w & NX_DUP)) continue;
+    auto count = [&](uint32_t w) {
+      if (w == NX_REJECT || (w & NX_DUP)) return;
       const uint32_t rl = w >> 24;
       const uint32_t thr = pp.apply_mmtol ? s_best[rl] + (uint32_t)pp.mmtol : 0xFFFFu;
       if ((w & 0xFFFFu) <= thr) atomicAdd(&s_cnt[rl], 1u);
-    }
+    };
+    count(w0);
+    for (uint32_t tj = threadIdx.x + TILE; tj < tn; tj += TILE)
+      count(tj - TILE < CODE_CAP ? s_code[tj - TILE] : p_nx[tb + tj]);
     if (block_mode) {
       for (uint32_t t = threadIdx.x; t < TILE * (uint32_t)pp.W; t += TILE) {
         const uint32_t cw = s_wcnt[t];
@@ -1070,20 +1086,27 @@ __global__ __launch_bounds__(TILE) void k_confirm(
     __syncthreads();
     // ---- pass 3
     if (total == 0) continue;
-    for (uint32_t tj = threadIdx.x; tj < tn; tj += TILE) {
-      const uint32_t w = tj < CODE_CAP ? s_code[tj] : p_nx[tb + tj];
-      if (w == NX_REJECT || (w & NX_DUP)) continue;
+    auto emit = [&](uint32_t w, uint32_t tj, uint32_t gene, uint32_t zword) {
+      if (w == NX_REJECT || (w & NX_DUP)) return;
       const uint32_t rl = w >> 24, v = w & 0xFFFFu;
       const uint32_t thr = pp.apply_mmtol ? s_best[rl] + (uint32_t)pp.mmtol : 0xFFFFu;
-      if (v > thr) continue;
+      if (v > thr) return;
       const uint32_t ord = atomicAdd(&s_cnt[rl], 1u);
-      const uint4 ds = cdesc[tb + tj];
       // position in the target: carried in the descriptor unless the target is so long that
-      // the entry's 16-bit distance saturated (then one gather of the gene's offset)
-      const uint32_t pos = ((ds.z >> 5) & 1u)
-                               ? ((ds.z >> 6) & 0xFFFFu)
-                               : (uint32_t)(((uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32)) - seq_off[ds.w]);
-      stage[tb + s_base[rl] + ord] = make_uint4((uint32_t)(r0 + tile * TILE + rl), ds.w, pos, v);
+      // the entry's 16-bit distance saturated (then the placement's offset minus the gene's)
+      uint32_t pos = (zword >> 6) & 0xFFFFu;
+      if (!((zword >> 5) & 1u)) {
+        const uint4 ds = cdesc[tb + tj];
+        pos = (uint32_t)(((uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32)) - seq_off[gene]);
+      }
+      stage[tb + s_base[rl] + ord] = make_uint4((uint32_t)(r0 + tile * TILE + rl), gene, pos, v);
+    };
+    emit(w0, threadIdx.x, gene0, z0);
+    for (uint32_t tj = threadIdx.x + TILE; tj < tn; tj += TILE) {
+      const uint32_t w = tj - TILE < CODE_CAP ? s_code[tj - TILE] : p_nx[tb + tj];
+      if (w == NX_REJECT || (w & NX_DUP)) continue;
+      const uint4 ds = cdesc[tb + tj];
+      emit(w, tj, ds.w, ds.z);
     }
   }
   block_add_u64(acc, &counters[1]);
