@@ -577,8 +577,9 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // Descriptor (16 B): x = read index within the batch (24 bits) | bits 32-39 of the placement's
 // global offset << 24, y = its low 32 bits, z = window | z-flag << 4 | pos_ok << 5 | position
 // in the target << 6 (when it fits 16 bits exactly), w = gene.
-// counters: [0] valid windows, [3] candidates (index entries walked), [4] pairs,
-//           [7] the largest number of descriptors any workgroup needed (region size to retry with).
+// counters (batch-local block = pass-level block + 8): [0] valid windows, [3] candidates (index
+//           entries walked), [4] pairs, [7] the largest number of descriptors any workgroup
+//           needed (region size to retry with); pass-level [3] is raised when a region ran out.
 #define SCR_OWN 2048  // overflow items per chunk whose owner is looked up directly
 #define SCR_PROBES (2 * TILE)  // probes per chunk: two windows of every read of the tile
 
@@ -847,6 +848,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
   if (threadIdx.x == 0) {
     atomicAdd(&counters[4], (unsigned long long)used);
     atomicMax(&counters[7], (unsigned long long)used);
+    if (used > region) atomicOr(&counters[3 - 8], 1ull);  // pass-level flag: descriptor space ran out
   }
 }
 
@@ -1124,8 +1126,12 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t ntiles, const uint32_t
                                                  const uint32_t* __restrict__ tcount2,
                                                  const uint32_t* __restrict__ tpre,
                                                  const uint4* __restrict__ stage, uint4* __restrict__ hits,
-                                                 const unsigned long long* __restrict__ counters) {
+                                                 uint64_t hits_cap, unsigned long long* __restrict__ counters) {
   const unsigned long long base = counters[2];
+  if (base + tpre[ntiles] > hits_cap) {  // cannot happen on a sized pass; a sync-free pass re-runs sized
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&counters[3], 2ull);
+    return;
+  }
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t m = tcount2[tile];
     const uint4* __restrict__ src = stage + tbase[tile];
@@ -1242,12 +1248,19 @@ struct musc_ctx {
   uint32_t last_max_matches = 0;
   bool last_exact_blocks = false;  // block_table holds exact counters of that pass
   unsigned long long* counters = nullptr;  // [0] valid windows [1] accepted [2] hit cursor
-  uint64_t* h_pinned = nullptr;            // 4 x u64 pinned staging
+  uint64_t* h_pinned = nullptr;            // 16 x u64 pinned staging
 
   DevBuf<musc_hit> hits;
   uint64_t nhits = 0;
 
   uint32_t batch_reads = 16u << 20;
+  // A pass over the same reads, database and parameters as the last completed one needs no
+  // sizing: its buffers are known to suffice, so it runs without host round trips.
+  uint64_t data_epoch = 1;       // bumped whenever reads or database change
+  uint64_t sized_epoch = 0;      // data_epoch of the last completed pass
+  musc_params sized_params;      // its parameters
+  bool sized_exact_blocks = false;
+  uint32_t sized_bsz = 0;        // reads per batch it ended up with
   musc_stats stats;
 };
 
@@ -1350,6 +1363,7 @@ void free_index(musc_ctx* c) {
   c->idx_E = nullptr;
   c->idx_ww = 0;
   c->idx_n = 0;
+  c->data_epoch++;
 }
 
 void free_db(musc_ctx* c) {
@@ -1361,6 +1375,7 @@ void free_db(musc_ctx* c) {
   c->seq_off = nullptr;
   c->nseq = 0;
   c->nbases = 0;
+  c->data_epoch++;
 }
 
 void free_reads(musc_ctx* c) {
@@ -1369,6 +1384,7 @@ void free_reads(musc_ctx* c) {
   c->rd = c->rdm = nullptr;
   c->nreads = 0;
   c->rw = 0;
+  c->data_epoch++;
 }
 
 struct EvPair {
@@ -1866,54 +1882,66 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
 
   // Per batch: k_screen claims descriptor space as it goes; if a batch needs more than the
   // buffer holds it reports how much and is repeated after growing the buffer (the first pass
-  // of a workload sizes it; steady-state passes never repeat).
+  // of a workload sizes it).  A pass over the same reads, database and parameters as the last
+  // completed one ("sized") is known to fit and runs without any host round trip; every kernel
+  // still guards its writes, and the flags are checked once at the end.
+  const bool sized = c->sized_epoch == c->data_epoch && c->sized_exact_blocks == (block_mode == 2) &&
+                     memcmp(&c->sized_params, P, sizeof *P) == 0 && !getenv("MUSC_DEBUG_SYNC");
   uint64_t n_cand = 0, n_pairs = 0, n_windows = 0;
   const uint64_t PAIR_CAP = 1ull << 31;  // u32 descriptor offsets
   uint64_t r0 = 0;
-  uint32_t bsz = c->batch_reads;
+  uint32_t bsz = sized ? c->sized_bsz : c->batch_reads;
+  if (sized) HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
   while (r0 < c->nreads) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
     const int W = pp.W;
     const uint32_t ntiles = nblk(n, TILE);
-    if ((rc = ensure(c, c->wb, (uint64_t)n * W))) return rc;
-    if ((rc = ensure(c, c->rvalid, (uint64_t)n + 1))) return rc;
-    if ((rc = ensure(c, c->tbase, (uint64_t)ntiles + 1))) return rc;
-    if ((rc = ensure(c, c->tcount, (uint64_t)ntiles + 1))) return rc;
-    if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)ntiles + 1)))) return rc;
-    if ((rc = ensure(c, c->tcount2, (uint64_t)ntiles + 1))) return rc;
-    if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
-    if ((rc = ensure(c, c->cdesc, std::max<uint64_t>(4ull * n, 1024)))) return rc;
+    uint64_t total = 1;  // pairs of this batch (unknown on a sized pass)
+    if (!sized) {
+      if ((rc = ensure(c, c->wb, (uint64_t)n * W))) return rc;
+      if ((rc = ensure(c, c->rvalid, (uint64_t)n + 1))) return rc;
+      if ((rc = ensure(c, c->tbase, (uint64_t)ntiles + 1))) return rc;
+      if ((rc = ensure(c, c->tcount, (uint64_t)ntiles + 1))) return rc;
+      if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)ntiles + 1)))) return rc;
+      if ((rc = ensure(c, c->tcount2, (uint64_t)ntiles + 1))) return rc;
+      if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
+      if ((rc = ensure(c, c->cdesc, std::max<uint64_t>(4ull * n, 1024)))) return rc;
+      // batch-local counters: [0] valid windows [3] candidates [4] pairs [7] descriptor cursor
+      HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
+    }
 
     tm.begin(0);
-    // batch-local counters: [0] valid windows [3] candidates [4] pairs [7] descriptor cursor
-    HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
     launch_stage(c, 0, mask, r0, n, pp);
     HIPCHK(c, hipGetLastError());
     tm.end(0);
-    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 8, 8 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&c->h_pinned[8], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const uint64_t total = c->h_pinned[4];  // pairs of this batch
-    const uint64_t hits_so_far = c->h_pinned[8];
-    const uint64_t sgrid = std::min(nblk(n, TILE), MAX_GRID);
-    const uint64_t need = c->h_pinned[7] * sgrid;  // every workgroup region as large as the fullest
-    if (need > PAIR_CAP) {
-      // too many pairs for one launch: retry this range with half the reads
-      if (n == 1) return fail(c, 6, "one read has %llu candidate pairs (> 2^31)", (unsigned long long)total);
-      bsz = n / 2;
-      continue;
-    }
-    if (c->h_pinned[7] > c->cdesc.cap / sgrid) {
-      if ((rc = ensure(c, c->cdesc, need + need / 8 + sgrid))) return rc;
-      continue;  // repeat the batch with room for every workgroup's pairs
+    if (!sized) {
+      HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 8, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(&c->h_pinned[8], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      total = c->h_pinned[4];
+      const uint64_t hits_so_far = c->h_pinned[8];
+      const uint64_t sgrid = std::min(nblk(n, TILE), MAX_GRID);
+      const uint64_t need = c->h_pinned[7] * sgrid;  // every workgroup region as large as the fullest
+      if (need > PAIR_CAP) {
+        // too many pairs for one launch: retry this range with half the reads
+        if (n == 1) return fail(c, 6, "one read has %llu candidate pairs (> 2^31)", (unsigned long long)total);
+        bsz = n / 2;
+        HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
+        continue;
+      }
+      if (c->h_pinned[7] > c->cdesc.cap / sgrid) {
+        if ((rc = ensure(c, c->cdesc, need + need / 8 + sgrid))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
+        continue;  // repeat the batch with room for every workgroup's pairs
+      }
+      n_windows += c->h_pinned[0];
+      n_cand += c->h_pinned[3];
+      n_pairs += c->h_pinned[4];
+      if ((rc = ensure(c, c->p_nx, c->cdesc.cap))) return rc;
+      if ((rc = ensure(c, c->stage, c->cdesc.cap))) return rc;
+      if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
     }
     c->stats.n_batches++;
-    n_windows += c->h_pinned[0];
-    n_cand += c->h_pinned[3];
-    n_pairs += c->h_pinned[4];
-    if ((rc = ensure(c, c->p_nx, c->cdesc.cap))) return rc;
-    if ((rc = ensure(c, c->stage, c->cdesc.cap))) return rc;
-    if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
 
     if (total) {
       const dim3 sg(std::min(nblk(n, TILE), MAX_GRID));
@@ -1930,7 +1958,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       if (rc) return rc;
       tm.end(1);
       hipLaunchKernelGGL(k_compact, sg, dim3(256), 0, c->stream, ntiles, c->tbase.p, c->tcount2.p, c->tpre.p,
-                         c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->counters);
+                         c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap, c->counters);
       HIPCHK(c, hipGetLastError());
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->tpre.p, ntiles, c->counters);
       HIPCHK(c, hipGetLastError());
@@ -1947,8 +1975,22 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipEventRecord(ev1, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 7 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 16 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (sized) {
+    if (c->h_pinned[3]) {
+      // a guard fired: the pass did not fit after all -- forget the sizing and run it the careful way
+      c->sized_epoch = 0;
+      (void)hipEventDestroy(ev0);
+      (void)hipEventDestroy(ev1);
+      return musc_match_device(c, P, nhits);
+    }
+    n_windows = c->h_pinned[8];  // the batch-local block accumulated over the whole pass
+    n_cand = c->h_pinned[8 + 3];
+    n_pairs = c->h_pinned[8 + 4];
+  } else if (c->h_pinned[3]) {
+    return fail(c, 12, "internal: capacity guard fired on a sized pass (flags %llu)", (unsigned long long)c->h_pinned[3]);
+  }
   c->stats.n_read_windows = n_windows;
   c->stats.n_accepted = c->h_pinned[1];
   c->stats.n_hits = c->nhits = c->h_pinned[2];
@@ -1979,6 +2021,10 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   const uint64_t L = c->max_len;
   c->stats.confirm_bytes = c->stats.n_pairs * (12 + (2 * L + 7) / 8 + (2 * L + 7) / 8 + 1);
   if (nhits) *nhits = c->nhits;
+  c->sized_epoch = c->data_epoch;
+  c->sized_params = *P;
+  c->sized_exact_blocks = block_mode == 2;
+  c->sized_bsz = bsz;
   return 0;
 }
 

@@ -217,6 +217,29 @@ def test_stats_and_repeat_calls_are_stable(eng):
     assert st["n_hits"] == len(a) and st["ms_total"] >= 0
 
 
+def test_repeated_passes_skip_sizing_and_stay_identical(eng):
+    """A pass over the same reads, database and parameters as the previous one runs without
+    host round trips (buffers already sized); it must give the same tuples and counters, and
+    new reads or parameters must take the careful path again."""
+    from muscato_amd import sorted_hits
+    keys = ("n_read_windows", "n_candidates", "n_pairs", "n_accepted", "n_hits", "n_overflow_blocks")
+    for seed in (3, 8, 21, 77):
+        ocfg, reads, targets = make_case(seed)
+        exp = as_arr(orc.match_direct(reads, targets, ocfg))
+        first = gpu_hits(eng, ocfg, reads, targets, False)
+        st0 = eng.stats()
+        assert_same(first, exp)
+        for _ in range(3):
+            assert_same(sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False)), exp)
+            st = eng.stats()
+            assert [st[k] for k in keys] == [st0[k] for k in keys]
+        best = as_arr(orc.best_filter(orc.match_direct(reads, targets, ocfg), ocfg.MMTol))
+        assert_same(sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=True)), best)
+        eng.load_reads(reads[: max(1, len(reads) // 2)])
+        half = as_arr(orc.match_direct(reads[: max(1, len(reads) // 2)], targets, ocfg))
+        assert_same(sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False)), half)
+
+
 def test_maxmatches_overflow_is_detected(eng):
     """cmd/muscato_confirm/main.go:233-242, 424-448: a (window,key) block with more than
     MaxMatches accepted pairs is truncated order-dependently by the reference.  The GPU path keeps
@@ -240,6 +263,18 @@ def test_maxmatches_overflow_is_detected(eng):
     c = orc.Config(Windows=[0, 1], WindowWidth=4, PMatch=0.5, MaxReadLength=50, MaxMatches=11)
     gpu_hits(eng, c, reads, targets, False)
     assert eng.stats()["n_overflow_blocks"] >= 1
+    assert eng.overflow_probes().tolist() == [[0, 0]]  # window 1 (CGTA) only matches targets 0, 4, 8
+    # both windows match every target: one descriptor stands for both windows of a placement and
+    # both blocks must still count it
+    targets = [b"ACGTA" + bytes([b"ACGT"[(i >> s) & 3] for s in (0, 2)]) + b"AAAA" for i in range(12)]
+    reads = [b"ACGTAAA"]
+    got = gpu_hits(eng, c, reads, targets, False)
+    assert_same(got, as_arr(orc.match_direct(reads, targets, c, check_overflow=False)))
+    assert len(got) == 12 and eng.stats()["n_overflow_blocks"] >= 1
+    assert sorted(eng.overflow_probes().tolist()) == [[0, 0], [0, 1]]
+    c.MaxMatches = 12
+    gpu_hits(eng, c, reads, targets, False)
+    assert eng.stats()["n_overflow_blocks"] == 0 and len(eng.overflow_probes()) == 0
 
 
 def test_no_overflow_reported_on_ordinary_cases(eng):
