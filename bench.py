@@ -265,12 +265,16 @@ def main() -> int:
             "roofline": {
                 "kernel": "k_confirm", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-                "traffic": measured_traffic(args.workload) if not args.reads else None, "bytes_per_pair": bytes_launch / max(st["n_pairs"] / max(st["confirm_launches"], 1), 1),
+                "traffic": measured_traffic(args.workload) if not args.reads else None,
+                "algorithmic_bytes": "63 B per candidate pair (12 descriptor + 25 read + 26 target span at 100 bp) + 16 B per tuple written",
                 "pairs_per_launch": st["n_pairs"] / max(st["confirm_launches"], 1),
+                "descriptors_per_launch": st["n_descriptors"] / max(st["confirm_launches"], 1),
+                "tuples_per_launch": st["n_hits"] / max(st["confirm_launches"], 1),
                 "avg_launch_ms": ms_launch, "launches_per_step": st["confirm_launches"],
             },
             "per_step": {
-                "candidates": st["n_candidates"], "pairs": st["n_pairs"], "accepted": st["n_accepted"], "hits": st["n_hits"],
+                "candidates": st["n_candidates"], "pairs": st["n_pairs"], "descriptors": st["n_descriptors"],
+                "accepted": st["n_accepted"], "hits": st["n_hits"],
                 "hits_on_rank0": gathered_n[0], "maxmatches_overflow_blocks": st["n_overflow_blocks"], "read_windows": st["n_read_windows"],
                 "ms_screen": acc["ms_screen"] / args.steps, "ms_scan": acc["ms_scan"] / args.steps,
                 "ms_confirm": acc["ms_confirm"] / args.steps,

@@ -84,24 +84,29 @@ typedef struct {
   uint64_t n_reads;         /* unique reads processed                                  */
   uint64_t n_read_windows;  /* (read, window) seeds that passed the length+entropy gate */
   uint64_t n_candidates;    /* index entries probed (k-mer hits incl. chance hits)      */
-  uint64_t n_pairs;         /* candidate pairs that reached the confirm kernel          */
+  uint64_t n_pairs;         /* (window, read, placement) candidate pairs that reached the
+                             * confirm kernel -- the reference's smatch/win join output,
+                             * minus what the flank filter already ruled out               */
   uint64_t n_accepted;      /* pairs with nmiss <= budget, after the union over windows */
   uint64_t n_hits;          /* tuples returned                                          */
   /* (window,key) blocks whose accepted pairs may exceed MaxMatches: 0 = proven none (the
    * reference's truncation, cmd/muscato_confirm/main.go:233-242, 424-448, never triggered and
    * the tuples are exact); > 0 = upper bound; ~0 = check skipped */
   uint64_t n_overflow_blocks;
-  uint64_t confirm_bytes;   /* algorithmic bytes of the confirm launches (63 B/pair at 100 bp) */
+  uint64_t confirm_bytes;   /* algorithmic bytes of the confirm launches: 63 B per candidate
+                             * pair at 100 bp + 16 B per tuple written      */
   uint32_t confirm_launches;
   uint32_t n_batches;
   float ms_screen;          /* HIP-event time of each kernel family, summed over batches:  */
-  float ms_scan;            /*   k_screen | scans | (unused) | k_confirm | k_select+k_emit  */
+  float ms_scan;            /*   k_screen | scan | (unused) | k_confirm | scan+k_compact   */
   float ms_unused0;
   float ms_confirm;
   float ms_select;
   float ms_total;           /* first launch to last completion on the context's stream  */
   float ms_index_build;     /* last musc_db_build_index                                 */
   float ms_reserved;
+  uint64_t n_descriptors;   /* descriptors k_screen wrote: one per placement of a read, also
+                             * when two windows of the read found it (then it is two pairs) */
 } musc_stats;
 
 int musc_abi_version(void);

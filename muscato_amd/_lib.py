@@ -45,6 +45,7 @@ class MuscStats(ctypes.Structure):
         ("ms_screen", ctypes.c_float), ("ms_scan", ctypes.c_float), ("ms_unused0", ctypes.c_float),
         ("ms_confirm", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_total", ctypes.c_float),
         ("ms_index_build", ctypes.c_float), ("ms_reserved", ctypes.c_float),
+        ("n_descriptors", ctypes.c_uint64),
     ]
 
 

@@ -484,6 +484,9 @@ struct Rec {
 };
 
 template <>
+struct Rec<-1> {};  // no record
+
+template <>
 struct Rec<0> {
   const uint32_t* __restrict__ p;
   int rw;
@@ -578,7 +581,7 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 // global offset << 24, y = its low 32 bits, z = window | z-flag << 4 | pos_ok << 5 | position
 // in the target << 6 (when it fits 16 bits exactly), w = gene.
 // counters (batch-local block = pass-level block + 8): [0] valid windows, [3] candidates (index
-//           entries walked), [4] pairs, [7] the largest number of descriptors any workgroup
+//           entries walked), [4] descriptors, [5] descriptors that stand for two windows, [7] the largest number of descriptors any workgroup
 //           needed (region size to retry with); pass-level [3] is raised when a region ran out.
 #define SCR_OWN 2048  // overflow items per chunk whose owner is looked up directly
 #define SCR_PROBES (2 * TILE)  // probes per chunk: two windows of every read of the tile
@@ -613,7 +616,7 @@ DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values der
 #ifndef SCR_WAVES
 #define SCR_WAVES 4  // waves per SIMD the register allocator has to leave room for
 #endif
-template <int RW>
+template <int RW, bool MASK>
 __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __restrict__ rd,
                                                  const uint32_t* __restrict__ rdm, uint64_t r0,
                                                  uint32_t n, int rw_rt, PathParams pp,
@@ -648,9 +651,9 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
   __shared__ uint16_t s_own[SCR_OWN];          // flat item -> probe
   __shared__ uint32_t s_tilecnt;               // survivors of the tile so far
   const int rw = RW ? RW : rw_rt;
-  const bool has_m = rdm != nullptr;
+  constexpr bool has_m = MASK;  // the mask planes exist (some read or target holds an X)
   const uint32_t ntiles = (n + TILE - 1) / TILE;
-  unsigned long long nvalid = 0, ncand = 0;
+  unsigned long long nvalid = 0, ncand = 0, ntwo = 0;
   const uint64_t region = desc_cap / gridDim.x;
   const uint64_t region0 = region * blockIdx.x;
   uint64_t used = 0;  // descriptors this workgroup has needed so far (uniform across the workgroup)
@@ -685,8 +688,11 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
     const uint64_t r = r0 + (active ? i : 0);
     Rec<RW> rec;
     rec.load(rd + r * (uint64_t)rw, rw);
-    Rec<RW> recm = rec;  // placeholder, only read under has_m
-    if (has_m) recm.load(rdm + r * (uint64_t)rw, rw);
+    Rec<has_m ? RW : -1> recm_store;
+    if constexpr (has_m) recm_store.load(rdm + r * (uint64_t)rw, rw);
+    const auto& recm = [&]() -> const Rec<RW>& {
+      if constexpr (has_m) return recm_store; else return rec;  // never read without a mask plane
+    }();
     const int len = (int)rec.len();
     const uint32_t budget = nmiss_tab[len];
     uint32_t valid = 0;
@@ -754,7 +760,8 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
         for (int rr = 0; rr < 4; rr++) {
           const uint32_t probe = wid * 128 + (4 * h + rr) * 16 + (lane >> 2);
           const uint32_t part = lane & 3;
-          const uint32_t cnt = __shfl(v[rr].x, lane & ~3);  // the header sits in the quad's first lane
+          // the header sits in the quad's first lane (quad_perm [0,0,0,0])
+          const uint32_t cnt = (uint32_t)__builtin_amdgcn_mov_dpp((int)v[rr].x, 0x00, 0xF, 0xF, true);
           if (part == 0) {
             ncand += cnt;
             s_oc[probe] = cnt > BUCKET_INLINE ? cnt - BUCKET_INLINE : 0u;
@@ -788,6 +795,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
           if (!ok || (pp.dbg & 8)) same = 0;
           const bool two = same && !odd;
           if (same && odd) ok = false;
+          ntwo += two;
           append(ok, v[rr], probe, k, q1, z, two);
         }
       }
@@ -845,6 +853,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
   }
   block_add_u64(nvalid, &counters[0]);
   block_add_u64(ncand, &counters[3]);
+  block_add_u64(ntwo, &counters[5]);
   if (threadIdx.x == 0) {
     atomicAdd(&counters[4], (unsigned long long)used);
     atomicMax(&counters[7], (unsigned long long)used);
@@ -1438,9 +1447,14 @@ template <int RW>
 void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp) {
   const dim3 block(TILE);
   if (stage == 0) {
-    hipLaunchKernelGGL((k_screen<RW>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd, c->rdm, r0,
-                       n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap, c->rvalid.p,
-                       c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
+    if (c->rdm)
+      hipLaunchKernelGGL((k_screen<RW, true>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd,
+                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap,
+                         c->rvalid.p, c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
+    else
+      hipLaunchKernelGGL((k_screen<RW, false>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd,
+                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap,
+                         c->rvalid.p, c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
   } else {
     // persistent over tiles; the MaxMatches screening threshold assumes at most MAX_GRID workgroups
     const dim3 grid(std::min(nblk(n, TILE), MAX_GRID));
@@ -1887,7 +1901,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   // still guards its writes, and the flags are checked once at the end.
   const bool sized = c->sized_epoch == c->data_epoch && c->sized_exact_blocks == (block_mode == 2) &&
                      memcmp(&c->sized_params, P, sizeof *P) == 0 && !getenv("MUSC_DEBUG_SYNC");
-  uint64_t n_cand = 0, n_pairs = 0, n_windows = 0;
+  uint64_t n_cand = 0, n_pairs = 0, n_windows = 0, n_two = 0;
   const uint64_t PAIR_CAP = 1ull << 31;  // u32 descriptor offsets
   uint64_t r0 = 0;
   uint32_t bsz = sized ? c->sized_bsz : c->batch_reads;
@@ -1937,6 +1951,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       n_windows += c->h_pinned[0];
       n_cand += c->h_pinned[3];
       n_pairs += c->h_pinned[4];
+      n_two += c->h_pinned[5];
       if ((rc = ensure(c, c->p_nx, c->cdesc.cap))) return rc;
       if ((rc = ensure(c, c->stage, c->cdesc.cap))) return rc;
       if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
@@ -1988,13 +2003,15 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     n_windows = c->h_pinned[8];  // the batch-local block accumulated over the whole pass
     n_cand = c->h_pinned[8 + 3];
     n_pairs = c->h_pinned[8 + 4];
+    n_two = c->h_pinned[8 + 5];
   } else if (c->h_pinned[3]) {
     return fail(c, 12, "internal: capacity guard fired on a sized pass (flags %llu)", (unsigned long long)c->h_pinned[3]);
   }
   c->stats.n_read_windows = n_windows;
   c->stats.n_accepted = c->h_pinned[1];
   c->stats.n_hits = c->nhits = c->h_pinned[2];
-  c->stats.n_pairs = n_pairs;
+  c->stats.n_descriptors = n_pairs;
+  c->stats.n_pairs = n_pairs + n_two;  // a two-window descriptor is two of the reference's candidate pairs
   c->stats.n_candidates = n_cand;
   // 0 = proven: no (window,key) block exceeded MaxMatches, the tuples equal the reference's;
   // otherwise an upper bound on the number of such blocks (or ~0ull when the check was skipped)
@@ -2017,9 +2034,10 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   (void)hipEventElapsedTime(&c->stats.ms_total, ev0, ev1);
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
-  // 12 B descriptor + ceil(2L/8) B read + ceil(2L/8)+1 B target span per pair
+  // 12 B descriptor + ceil(2L/8) B read + ceil(2L/8)+1 B target span per
+  // candidate pair, + 16 B per tuple written
   const uint64_t L = c->max_len;
-  c->stats.confirm_bytes = c->stats.n_pairs * (12 + (2 * L + 7) / 8 + (2 * L + 7) / 8 + 1);
+  c->stats.confirm_bytes = c->stats.n_pairs * (12 + (2 * L + 7) / 8 + (2 * L + 7) / 8 + 1) + 16 * c->stats.n_hits;
   if (nhits) *nhits = c->nhits;
   c->sized_epoch = c->data_epoch;
   c->sized_params = *P;
