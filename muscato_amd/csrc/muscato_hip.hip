@@ -613,6 +613,9 @@ DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values der
   return x;
 }
 
+#ifndef SCR_ROUNDS
+#define SCR_ROUNDS 4  // quad rounds whose bucket loads are in flight together (8 per chunk)
+#endif
 #ifndef SCR_WAVES
 #define SCR_WAVES 4  // waves per SIMD the register allocator has to leave room for
 #endif
@@ -746,19 +749,19 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       __syncthreads();
       // ---- phase B: buckets by quads; a wave fetches the 128 probes of its own 64 reads
 #pragma unroll 1
-      for (int h = 0; h < ((pp.dbg & 256) ? 0 : 2); h++) {
+      for (int h = 0; h < ((pp.dbg & 256) ? 0 : 8 / SCR_ROUNDS); h++) {
         const uint32_t tidb = opaque(threadIdx.x);
         const uint32_t lane = tidb & 63, wid = tidb >> 6;
-        uint4 v[4];
+        uint4 v[SCR_ROUNDS];
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const uint32_t b = s_bb[wid * 128 + (4 * h + rr) * 16 + (lane >> 2)];
+        for (int rr = 0; rr < SCR_ROUNDS; rr++) {
+          const uint32_t b = s_bb[wid * 128 + (SCR_ROUNDS * h + rr) * 16 + (lane >> 2)];
           v[rr] = make_uint4(0, 0, 0, 0);
           if (b != WB_NONE && !(pp.dbg & 2)) v[rr] = reinterpret_cast<const uint4*>(T + b)[lane & 3];
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const uint32_t probe = wid * 128 + (4 * h + rr) * 16 + (lane >> 2);
+        for (int rr = 0; rr < SCR_ROUNDS; rr++) {
+          const uint32_t probe = wid * 128 + (SCR_ROUNDS * h + rr) * 16 + (lane >> 2);
           const uint32_t part = lane & 3;
           // the header sits in the quad's first lane (quad_perm [0,0,0,0])
           const uint32_t cnt = (uint32_t)__builtin_amdgcn_mov_dpp((int)v[rr].x, 0x00, 0xF, 0xF, true);
@@ -1245,8 +1248,18 @@ struct musc_ctx {
   uint32_t max_len = 0;
 
   // per-batch work buffers
-  DevBuf<uint32_t> wb, rvalid, tbase, tcount, scan_tmp, tcount2, tpre;
-  DevBuf<uint4> cdesc, stage;
+  // what k_screen hands to k_confirm, twice: in a pipelined pass k_screen fills one set on the
+  // screen stream while k_confirm and k_compact drain the other on the confirm stream
+  struct BatchSet {
+    DevBuf<uint32_t> wb, rvalid, tbase, tcount;
+    DevBuf<uint4> cdesc;
+  } bs[2];
+  int cur = 0;                     // the set the next launches use
+  hipStream_t stream2 = nullptr;   // confirm stream of a pipelined pass
+  hipStream_t s_confirm = nullptr; // where k_confirm .. k_advance go in the pass in flight
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_join = nullptr;
+  DevBuf<uint32_t> scan_tmp, tcount2, tpre;
+  DevBuf<uint4> stage;
   DevBuf<uint32_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
   DevBuf<uint32_t> block_table;
@@ -1327,22 +1340,24 @@ uint64_t scan_tmp_elems(uint64_t n) {
   return t + 8;
 }
 
-int scan_u32(musc_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, bool inclusive, uint32_t* tmp) {
+int scan_u32(musc_ctx* c, const uint32_t* in, uint32_t* out, uint64_t n, bool inclusive, uint32_t* tmp,
+             hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
   const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb > 0x7FFFFFFFull) return fail(c, 11, "scan too large");
   if (nb <= 1) {
-    if (inclusive) hipLaunchKernelGGL(k_scan_block<true>, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, in, out, (uint32_t*)nullptr, n);
-    else hipLaunchKernelGGL(k_scan_block<false>, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, in, out, (uint32_t*)nullptr, n);
+    if (inclusive) hipLaunchKernelGGL(k_scan_block<true>, dim3(1), dim3(SCAN_BLOCK), 0, st, in, out, (uint32_t*)nullptr, n);
+    else hipLaunchKernelGGL(k_scan_block<false>, dim3(1), dim3(SCAN_BLOCK), 0, st, in, out, (uint32_t*)nullptr, n);
     HIPCHK(c, hipGetLastError());
     return 0;
   }
   uint32_t* sums = tmp;
-  if (inclusive) hipLaunchKernelGGL(k_scan_block<true>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, out, sums, n);
-  else hipLaunchKernelGGL(k_scan_block<false>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, in, out, sums, n);
+  if (inclusive) hipLaunchKernelGGL(k_scan_block<true>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, out, sums, n);
+  else hipLaunchKernelGGL(k_scan_block<false>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, out, sums, n);
   HIPCHK(c, hipGetLastError());
-  int rc = scan_u32(c, sums, sums, nb, false, tmp + ((nb + 8 + 3) & ~3ull));
+  int rc = scan_u32(c, sums, sums, nb, false, tmp + ((nb + 8 + 3) & ~3ull), st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, c->stream, out, sums, n);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, out, sums, n);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1404,14 +1419,14 @@ struct Timer {
   musc_ctx* c;
   std::vector<EvPair> ev[5];
   explicit Timer(musc_ctx* ctx) : c(ctx) {}
-  int begin(int fam) {
+  int begin(int fam, hipStream_t s = nullptr) {
     EvPair p;
     if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return 1;
-    (void)hipEventRecord(p.a, c->stream);
+    (void)hipEventRecord(p.a, s ? s : c->stream);
     ev[fam].push_back(p);
     return 0;
   }
-  void end(int fam) { (void)hipEventRecord(ev[fam].back().b, c->stream); }
+  void end(int fam, hipStream_t s = nullptr) { (void)hipEventRecord(ev[fam].back().b, s ? s : c->stream); }
   float total(int fam) {
     float t = 0;
     for (auto& p : ev[fam]) {
@@ -1449,25 +1464,25 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
   if (stage == 0) {
     if (c->rdm)
       hipLaunchKernelGGL((k_screen<RW, true>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd,
-                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap,
-                         c->rvalid.p, c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
+                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,
+                         c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, c->counters + 8);
     else
       hipLaunchKernelGGL((k_screen<RW, false>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd,
-                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->cdesc.p, c->cdesc.cap,
-                         c->rvalid.p, c->wb.p, c->tbase.p, c->tcount.p, c->counters + 8);
+                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,
+                         c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, c->counters + 8);
   } else {
     // persistent over tiles; the MaxMatches screening threshold assumes at most MAX_GRID workgroups
     const dim3 grid(std::min(nblk(n, TILE), MAX_GRID));
     const size_t lds = c->cur_block_mode ? (size_t)TILE * pp.W * 4 : 0;
     if (mask)
-      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, lds, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p,
-                         c->wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
+      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
+                         c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p, c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
+                         c->bs[c->cur].wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
                          c->tcount2.p, c->counters);
     else
-      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, lds, c->stream, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
-                         c->rw, pp, c->nmiss_tab.p, c->cdesc.p, c->rvalid.p, c->p_nx.p, c->tbase.p, c->tcount.p,
-                         c->wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
+      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
+                         c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p, c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
+                         c->bs[c->cur].wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
                          c->tcount2.p, c->counters);
   }
 }
@@ -1512,11 +1527,21 @@ int musc_init(int device_ordinal, musc_ctx** out) {
   c->device = device_ordinal;
   memset(&c->stats, 0, sizeof c->stats);
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_ready[0], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_ready[1], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_free[0], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_free[1], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
       (e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(uint64_t))) != hipSuccess) {
     fail(nullptr, 3, "musc_init: %s", hipGetErrorString(e));
     musc_destroy(c);
     return 3;
+  }
+  if (const char* br = getenv("MUSC_BATCH_READS")) {  // tests: many small batches
+    const long v = atol(br);
+    if (v >= 1 && v <= (16l << 20)) c->batch_reads = (uint32_t)v;
   }
   *out = c;
   return 0;
@@ -1526,16 +1551,23 @@ void musc_destroy(musc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   free_db(c);
   free_reads(c);
-  c->wb.release(); c->tbase.release();
+  for (int i = 0; i < 2; i++) {
+    c->bs[i].wb.release(); c->bs[i].tbase.release(); c->bs[i].rvalid.release(); c->bs[i].tcount.release();
+    c->bs[i].cdesc.release();
+  }
   c->scan_tmp.release(); c->tcount2.release(); c->tpre.release(); c->stage.release();
-  c->rvalid.release(); c->tcount.release(); c->cdesc.release(); c->p_nx.release();
+  c->p_nx.release();
   c->nmiss_tab.release();
   c->block_table.release();
   c->hits.release();
   if (c->counters) (void)hipFree(c->counters);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (hipEvent_t ev : {c->ev_ready[0], c->ev_ready[1], c->ev_free[0], c->ev_free[1], c->ev_join})
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1906,20 +1938,41 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   uint64_t r0 = 0;
   uint32_t bsz = sized ? c->sized_bsz : c->batch_reads;
   if (sized) HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
+  // MUSC_PIPELINE=1: a sized pass of several batches is pipelined over two streams, k_screen of
+  // batch b+1 beside k_confirm + k_compact of batch b, alternating between the two batch sets.
+  // Off by default: measured on cfg3 / cfg4 / cfg5 shards the pass moves ~5.6 TB/s of cache lines
+  // through HBM either way (both kernels are bound by the lines they fetch), so overlapping them
+  // gains nothing (5.66 vs 5.44 ms on cfg3) and the second set costs memory.
+  const char* pipe_env = getenv("MUSC_PIPELINE");
+  const bool want_pipe = pipe_env && atoi(pipe_env) > 0;
+  const bool piped = sized && want_pipe && c->nreads > bsz && c->bs[1].cdesc.cap >= c->bs[0].cdesc.cap;
+  hipStream_t sA = c->stream, sB = piped ? c->stream2 : c->stream;
+  c->s_confirm = sB;
+  c->cur = 0;
+  if (piped) {  // the confirm stream starts after the memsets above
+    HIPCHK(c, hipEventRecord(c->ev_join, sA));
+    HIPCHK(c, hipStreamWaitEvent(sB, c->ev_join, 0));
+  }
+  uint32_t batch_no = 0;
   while (r0 < c->nreads) {
     const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
+    if (piped) {
+      c->cur = (int)(batch_no & 1u);
+      // the set is free once the batch before last has been compacted
+      if (batch_no >= 2) HIPCHK(c, hipStreamWaitEvent(sA, c->ev_free[c->cur], 0));
+    }
     const int W = pp.W;
     const uint32_t ntiles = nblk(n, TILE);
     uint64_t total = 1;  // pairs of this batch (unknown on a sized pass)
     if (!sized) {
-      if ((rc = ensure(c, c->wb, (uint64_t)n * W))) return rc;
-      if ((rc = ensure(c, c->rvalid, (uint64_t)n + 1))) return rc;
-      if ((rc = ensure(c, c->tbase, (uint64_t)ntiles + 1))) return rc;
-      if ((rc = ensure(c, c->tcount, (uint64_t)ntiles + 1))) return rc;
+      if ((rc = ensure(c, c->bs[c->cur].wb, (uint64_t)n * W))) return rc;
+      if ((rc = ensure(c, c->bs[c->cur].rvalid, (uint64_t)n + 1))) return rc;
+      if ((rc = ensure(c, c->bs[c->cur].tbase, (uint64_t)ntiles + 1))) return rc;
+      if ((rc = ensure(c, c->bs[c->cur].tcount, (uint64_t)ntiles + 1))) return rc;
       if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)ntiles + 1)))) return rc;
       if ((rc = ensure(c, c->tcount2, (uint64_t)ntiles + 1))) return rc;
       if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
-      if ((rc = ensure(c, c->cdesc, std::max<uint64_t>(4ull * n, 1024)))) return rc;
+      if ((rc = ensure(c, c->bs[c->cur].cdesc, std::max<uint64_t>(4ull * n, 1024)))) return rc;
       // batch-local counters: [0] valid windows [3] candidates [4] pairs [7] descriptor cursor
       HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
     }
@@ -1928,6 +1981,10 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     launch_stage(c, 0, mask, r0, n, pp);
     HIPCHK(c, hipGetLastError());
     tm.end(0);
+    if (piped) {
+      HIPCHK(c, hipEventRecord(c->ev_ready[c->cur], sA));
+      HIPCHK(c, hipStreamWaitEvent(sB, c->ev_ready[c->cur], 0));
+    }
     if (!sized) {
       HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters + 8, 8 * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync(&c->h_pinned[8], c->counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1943,8 +2000,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
         HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
         continue;
       }
-      if (c->h_pinned[7] > c->cdesc.cap / sgrid) {
-        if ((rc = ensure(c, c->cdesc, need + need / 8 + sgrid))) return rc;
+      if (c->h_pinned[7] > c->bs[c->cur].cdesc.cap / sgrid) {
+        if ((rc = ensure(c, c->bs[c->cur].cdesc, need + need / 8 + sgrid))) return rc;
         HIPCHK(c, hipMemsetAsync(c->counters + 3, 0, 8, c->stream));
         continue;  // repeat the batch with room for every workgroup's pairs
       }
@@ -1952,8 +2009,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       n_cand += c->h_pinned[3];
       n_pairs += c->h_pinned[4];
       n_two += c->h_pinned[5];
-      if ((rc = ensure(c, c->p_nx, c->cdesc.cap))) return rc;
-      if ((rc = ensure(c, c->stage, c->cdesc.cap))) return rc;
+      if ((rc = ensure(c, c->p_nx, c->bs[c->cur].cdesc.cap))) return rc;
+      if ((rc = ensure(c, c->stage, c->bs[c->cur].cdesc.cap))) return rc;
       if ((rc = ensure(c, c->hits, hits_so_far + total, true))) return rc;
     }
     c->stats.n_batches++;
@@ -1961,26 +2018,34 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if (total) {
       const dim3 sg(std::min(nblk(n, TILE), MAX_GRID));
 
-      tm.begin(3);
+      tm.begin(3, sB);
       launch_stage(c, 2, mask, r0, n, pp);
       HIPCHK(c, hipGetLastError());
-      tm.end(3);
+      tm.end(3, sB);
       c->stats.confirm_launches++;
 
-      tm.begin(4);
-      tm.begin(1);
-      rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p);
+      tm.begin(4, sB);
+      tm.begin(1, sB);
+      rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p, sB);
       if (rc) return rc;
-      tm.end(1);
-      hipLaunchKernelGGL(k_compact, sg, dim3(256), 0, c->stream, ntiles, c->tbase.p, c->tcount2.p, c->tpre.p,
+      tm.end(1, sB);
+      hipLaunchKernelGGL(k_compact, sg, dim3(256), 0, sB, ntiles, c->bs[c->cur].tbase.p, c->tcount2.p, c->tpre.p,
                          c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap, c->counters);
       HIPCHK(c, hipGetLastError());
-      hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->tpre.p, ntiles, c->counters);
+      hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, sB, c->tpre.p, ntiles, c->counters);
       HIPCHK(c, hipGetLastError());
-      tm.end(4);
+      tm.end(4, sB);
     }
+    if (piped) HIPCHK(c, hipEventRecord(c->ev_free[c->cur], sB));
     r0 += n;
+    batch_no++;
   }
+  if (piped) {  // join: everything below is ordered after both streams
+    HIPCHK(c, hipEventRecord(c->ev_join, sB));
+    HIPCHK(c, hipStreamWaitEvent(sA, c->ev_join, 0));
+  }
+  c->cur = 0;
+  c->s_confirm = c->stream;
   c->last_pp = pp;
   c->last_max_matches = (uint32_t)max_matches;
   c->last_exact_blocks = block_mode == 2;
@@ -2039,6 +2104,12 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   const uint64_t L = c->max_len;
   c->stats.confirm_bytes = c->stats.n_pairs * (12 + (2 * L + 7) / 8 + (2 * L + 7) / 8 + 1) + 16 * c->stats.n_hits;
   if (nhits) *nhits = c->nhits;
+  if (!sized && want_pipe) {  // the second batch set gets the capacities the first one ended up with
+    if ((rc = ensure(c, c->bs[1].wb, c->bs[0].wb.cap)) || (rc = ensure(c, c->bs[1].rvalid, c->bs[0].rvalid.cap)) ||
+        (rc = ensure(c, c->bs[1].tbase, c->bs[0].tbase.cap)) || (rc = ensure(c, c->bs[1].tcount, c->bs[0].tcount.cap)) ||
+        (rc = ensure(c, c->bs[1].cdesc, c->bs[0].cdesc.cap)))
+      return rc;
+  }
   c->sized_epoch = c->data_epoch;
   c->sized_params = *P;
   c->sized_exact_blocks = block_mode == 2;

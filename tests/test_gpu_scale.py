@@ -135,3 +135,27 @@ def test_shard_invariance(eng, workload):
         parts.append(h)
     cat = sorted_hits(np.concatenate(parts))
     assert cat.shape == whole.shape and (cat == whole).all()
+
+
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_many_batches_equal_one_batch(workload, eng, monkeypatch, pipeline):
+    """Many small batches: the first pass sizes them one by one, repeated passes run without host
+    round trips -- on one stream, or (MUSC_PIPELINE=1) over two streams with k_screen of batch b+1
+    beside k_confirm of batch b.  All must give the single-batch tuples."""
+    from muscato_amd import Engine, sorted_hits
+    R, T = workload["R"], workload["T"]
+    load_reads(eng, R)
+    whole = sorted_hits(eng.match(cfg(mmtol=1), apply_mmtol=True))
+    monkeypatch.setenv("MUSC_BATCH_READS", "70001")  # read at musc_init; not a multiple of the tile
+    monkeypatch.setenv("MUSC_PIPELINE", pipeline)
+    e2 = Engine(0)
+    try:
+        toff = np.arange(N_TARGETS + 1, dtype=np.uint64) * np.uint64(TLEN)
+        e2.load_targets_arrays(np.concatenate([T.reshape(-1), np.zeros(8, np.uint8)]), toff)
+        load_reads(e2, R)
+        for rep in range(3):  # pass 0 sizes, passes 1-2 are sync-free
+            got = sorted_hits(e2.match(cfg(mmtol=1), apply_mmtol=True))
+            assert e2.stats()["n_batches"] == -(-len(R) // 70001)
+            assert got.shape == whole.shape and (got == whole).all(), "pass %d differs" % rep
+    finally:
+        e2.close()
