@@ -349,6 +349,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan64_add(uint64_t* __restrict_
 //   w flank  : the 8 bases left of the window (bits 0-15, base jx-1 in bits 14-15) and the
 //              8 bases right of it (bits 16-31, base jx+ww in bits 16-17), 2 bits each
 // ------------------------------------------------------------------------------------
+typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
 #define BUCKET_INLINE 3
 struct __attribute__((aligned(64))) Bucket {
   uint32_t count;
@@ -757,7 +758,11 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
         for (int rr = 0; rr < SCR_ROUNDS; rr++) {
           const uint32_t b = s_bb[wid * 128 + (SCR_ROUNDS * h + rr) * 16 + (lane >> 2)];
           v[rr] = make_uint4(0, 0, 0, 0);
-          if (b != WB_NONE && !(pp.dbg & 2)) v[rr] = reinterpret_cast<const uint4*>(T + b)[lane & 3];
+          if (b != WB_NONE && !(pp.dbg & 2)) {
+            // non-temporal: a bucket is used once (measured: random 64-B fetches run 12 % faster)
+            const u32x4_v t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(T + b) + (lane & 3));
+            v[rr] = make_uint4(t.x, t.y, t.z, t.w);
+          }
         }
 #pragma unroll
         for (int rr = 0; rr < SCR_ROUNDS; rr++) {
@@ -833,7 +838,8 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
               }
               seg = lo;
             }
-            ent = E[s_ovf[seg] + (t - s_pref[seg])];
+            const u32x4_v te = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(E) + s_ovf[seg] + (t - s_pref[seg]));
+            ent = make_uint4(te.x, te.y, te.z, te.w);
             k = k0 + (int)(seg & 1u);
             q1 = (seg & 1u) ? q1b : q1a;
             ok = screen_entry_ok(ent, q1, pp.ww, s_rfl[seg], s_lenbud[seg], &z);
@@ -873,7 +879,6 @@ DEV uint32_t window_word_mask(int q1, int ww, int j) {
   return mh & ml;
 }
 
-typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
 
 // 16 bytes at a dword-aligned address (global memory allows it on gfx950)
 struct __attribute__((packed, aligned(4))) u32x4_u {
