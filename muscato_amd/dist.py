@@ -50,3 +50,78 @@ def gather_hits(local: torch.Tensor, read_base: int, dst: int = 0, group=None) -
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
     dist.gather(padded, gather_list=None, dst=dst, group=group)
     return None
+
+
+class HitGatherer:
+    """Streaming form of gather_hits for a sequence of passes (bench.py --gpus N, a service
+    matching batch after batch): one collective per pass, no host round trip, and the gather of
+    pass i runs on the communicator's stream while pass i+1 is being matched.
+
+    Every rank owns `depth` send buffers of `cap` + 1 rows; row `cap` carries the tuple count, so
+    no separate exchange of counts is needed.  Rank `dst` owns `depth` sets of receive buffers.
+    submit() fills the next send buffer through `fill(buf_rows) -> n` (e.g. Engine.hits_to),
+    rebases column 0 by `read_base` and starts an asynchronous gather; it first waits for the
+    gather issued `depth` passes earlier, whose buffers it reuses.  finish() waits for
+    everything; on `dst`, counts(k) / last_result() then give the tuples per rank -- rank-order
+    concatenation is the global read order."""
+
+    def __init__(self, cap: int, device, depth: int = 2, dst: int = 0, group=None, dtype=torch.int32):
+        self.cap, self.depth, self.dst, self.group = int(cap), depth, dst, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.send = [torch.zeros((self.cap + 1, 4), dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = None
+        if self.rank == dst:
+            self.recv = [[torch.empty((self.cap + 1, 4), dtype=dtype, device=device) for _ in range(self.world)]
+                         for _ in range(depth)]
+        self.work = [None] * depth
+        self.i = 0
+
+    @staticmethod
+    def agree_capacity(n_local: int, device, slack: float = 1.05, group=None) -> int:
+        """A capacity every rank's hit list fits in: max over ranks, plus slack."""
+        t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return int(int(t.item()) * slack) + 16
+
+    def submit(self, fill, read_base: int) -> int:
+        k = self.i % self.depth
+        if self.work[k] is not None:
+            self.work[k].wait()
+            if self.send[k].is_cuda:
+                torch.cuda.current_stream().synchronize()  # fill() may write from another stream
+            self.work[k] = None
+        buf = self.send[k]
+        n = int(fill(buf))
+        if n > self.cap:
+            raise RuntimeError("HitGatherer: %d hits exceed the agreed capacity %d" % (n, self.cap))
+        if read_base and n:
+            buf[:n, 0] += read_base
+        buf[self.cap, 0] = n
+        self.work[k] = dist.gather(buf, gather_list=self.recv[k] if self.rank == self.dst else None,
+                                   dst=self.dst, group=self.group, async_op=True)
+        self.i += 1
+        return n
+
+    def counts(self, k: int) -> List[int]:
+        """Tuple counts per rank of buffer set k (rank dst, after its gather completed)."""
+        return [int(b[self.cap, 0].item()) for b in self.recv[k]]
+
+    def finish(self) -> Optional[List[int]]:
+        """Wait for all outstanding gathers; on dst return the per-rank counts of the last pass."""
+        for k in range(self.depth):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+        if self.send[0].is_cuda:
+            torch.cuda.current_stream().synchronize()
+        if self.rank != self.dst or self.i == 0:
+            return None
+        return self.counts((self.i - 1) % self.depth)
+
+    def last_result(self) -> Optional[torch.Tensor]:
+        """After finish(): the last pass's tuples on dst, concatenated in rank order."""
+        if self.rank != self.dst or self.i == 0:
+            return None
+        k = (self.i - 1) % self.depth
+        return torch.cat([b[:c] for b, c in zip(self.recv[k], self.counts(k))], dim=0)

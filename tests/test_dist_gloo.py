@@ -86,3 +86,57 @@ def test_gather_single_rank_is_identity():
         assert t.tolist() == [[0, 1, 2, 3], [4, 5, 6, 7]]
     finally:
         dist.destroy_process_group()
+
+
+def _stream_worker(rank, world, port, outdir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from muscato_amd.dist import HitGatherer
+
+    def tuples(p):  # pass p, this rank: a different number of tuples every time
+        n = 5 + 3 * rank + 2 * p
+        t = torch.arange(n * 4, dtype=torch.int32).reshape(n, 4) + 1000 * p
+        t[:, 0] = torch.arange(n, dtype=torch.int32)  # shard-local read index
+        return t
+
+    cap = HitGatherer.agree_capacity(5 + 3 * rank + 2 * 4, torch.device("cpu"), slack=1.0)
+    g = HitGatherer(cap, torch.device("cpu"), depth=2)
+    snaps = []
+    for p in range(5):
+        t = tuples(p)
+
+        def fill(buf, t=t):
+            buf[:len(t)] = t
+            return len(t)
+        assert g.submit(fill, read_base=100 * rank) == len(t)
+        if p == 2:  # look at a finished pass in the middle of the stream
+            cn = g.finish()
+            if rank == 0:
+                snaps.append((cn, g.last_result().clone()))
+    cn = g.finish()
+    if rank == 0:
+        snaps.append((cn, g.last_result().clone()))
+        torch.save(snaps, os.path.join(outdir, "snaps.pt"))
+    with pytest.raises(RuntimeError):
+        g.submit(lambda buf: cap + 1, 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_streaming_gatherer_two_ranks(tmp_path):
+    """HitGatherer: overlapped per-pass gathers with counts riding in the buffers (what
+    bench.py --gpus N uses); buffers are reused every `depth` passes."""
+    mp.spawn(_stream_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    snaps = torch.load(tmp_path / "snaps.pt")
+    for (cn, res), p in zip(snaps, (2, 4)):
+        exp = []
+        for rank in range(2):
+            n = 5 + 3 * rank + 2 * p
+            t = torch.arange(n * 4, dtype=torch.int32).reshape(n, 4) + 1000 * p
+            t[:, 0] = torch.arange(n, dtype=torch.int32) + 100 * rank
+            exp.append(t)
+        assert cn == [len(e) for e in exp]
+        assert torch.equal(res, torch.cat(exp))
