@@ -104,7 +104,7 @@ typedef struct {
   float ms_select;
   float ms_total;           /* first launch to last completion on the context's stream  */
   float ms_index_build;     /* last musc_db_build_index                                 */
-  float ms_reserved;
+  float ms_read_prep;       /* last musc_reads_sort_unique (device time)                   */
   uint64_t n_descriptors;   /* descriptors k_screen wrote: one per placement of a read, also
                              * when two windows of the read found it (then it is two pairs) */
 } musc_stats;
@@ -145,6 +145,21 @@ int musc_reads_load_ascii(musc_ctx* ctx, const char* seqs, const uint64_t* offse
                           uint64_t nreads, int on_device);
 int musc_reads_load_packed(musc_ctx* ctx, const uint8_t* bases2bit, const uint8_t* nmask,
                            const uint64_t* read_offsets, uint64_t nreads);
+
+/* Read prep on the GPU: replaces the bytewise sort of the prepared reads (sortReads in
+ * cmd/muscato/main.go: GNU sort of the `seq\tname` lines under LC_ALL=C) and the collapse of
+ * identical sequences (cmd/muscato_uniqify/main.go:83-135) for the sequence column.
+ * Input: nreads reads as they leave muscato_prep_reads (non-ACGT -> X, length filter, truncated),
+ * in input order, ASCII + offsets like musc_reads_load_ascii.
+ * Afterwards the context's reads are the DISTINCT sequences in bytewise order (a proper prefix
+ * first), exactly as if the first column of reads_sorted.txt.sz had been loaded, and
+ *   order[nreads]       input read numbers sorted by sequence, ties in input order
+ *   ustart[*nunique+1]  distinct sequence g = the input reads order[ustart[g] .. ustart[g+1])
+ * so the host can write `seq\tcount\tnames` (count = group size; the reference's name order within
+ * a group is the bytewise order of the names, which the caller applies).  Both arrays are
+ * malloc'ed by the library: musc_free_u32. */
+int musc_reads_sort_unique(musc_ctx* ctx, const char* seqs, const uint64_t* offsets, uint64_t nreads,
+                           int on_device, uint32_t** order, uint32_t** ustart, uint64_t* nunique);
 
 /* ---- the hot path: screen + confirm (+ per-read best filter) -------------------------
  * musc_match_device leaves the hits in device memory (count in *nhits);

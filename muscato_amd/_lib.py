@@ -44,7 +44,7 @@ class MuscStats(ctypes.Structure):
         ("confirm_launches", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),
         ("ms_screen", ctypes.c_float), ("ms_scan", ctypes.c_float), ("ms_unused0", ctypes.c_float),
         ("ms_confirm", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_total", ctypes.c_float),
-        ("ms_index_build", ctypes.c_float), ("ms_reserved", ctypes.c_float),
+        ("ms_index_build", ctypes.c_float), ("ms_read_prep", ctypes.c_float),
         ("n_descriptors", ctypes.c_uint64),
     ]
 
@@ -53,7 +53,7 @@ class MuscStats(ctypes.Structure):
 SYMBOLS = [
     "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error",
     "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
-    "musc_reads_load_ascii", "musc_reads_load_packed",
+    "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique",
     "musc_match_device", "musc_hits_copy", "musc_match", "musc_free_hits",
     "musc_get_stats", "musc_gather", "musc_overflow_probes", "musc_free_u32",
 ]
@@ -86,6 +86,8 @@ def load() -> ctypes.CDLL:
     lib.musc_db_build_index.argtypes = [vp, i32]
     lib.musc_reads_load_ascii.argtypes = [vp, vp, vp, u64, ctypes.c_int]
     lib.musc_reads_load_packed.argtypes = [vp, vp, vp, vp, u64]
+    lib.musc_reads_sort_unique.argtypes = [vp, vp, vp, u64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                           ctypes.POINTER(u64)]
     lib.musc_match_device.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(u64)]
     lib.musc_hits_copy.argtypes = [vp, vp, u64, ctypes.c_int]
     lib.musc_match.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(vp), ctypes.POINTER(u64)]
@@ -99,7 +101,7 @@ def load() -> ctypes.CDLL:
     lib.musc_gather.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(u64),
                                 ctypes.POINTER(vp), ctypes.POINTER(u64)]
     for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
-                 "musc_reads_load_ascii", "musc_reads_load_packed", "musc_match_device",
+                 "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique", "musc_match_device",
                  "musc_hits_copy", "musc_match", "musc_get_stats", "musc_gather"):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib

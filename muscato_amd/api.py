@@ -213,6 +213,28 @@ class Engine:
         self._check(self._lib.musc_reads_load_ascii(self._h, seqs_ptr, off_ptr, nreads, 1), "musc_reads_load_ascii")
         self.n_reads = nreads
 
+    def sort_unique_reads(self, seqs: Sequence[bytes]):
+        """Read prep on the GPU (musc_reads_sort_unique): `seqs` are prepared reads in input order.
+        Loads the distinct sequences in bytewise order as the context's reads and returns
+        (order uint32[n], ustart uint32[n_unique + 1]): distinct sequence g stands for the input
+        reads order[ustart[g]:ustart[g+1]]."""
+        buf, off = concat(seqs)
+        return self.sort_unique_reads_arrays(buf.ctypes.data, off.ctypes.data, len(off) - 1, False)
+
+    def sort_unique_reads_arrays(self, seqs_ptr: int, off_ptr: int, nreads: int, on_device: bool):
+        po, pu, nu = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        self._check(self._lib.musc_reads_sort_unique(self._h, seqs_ptr, off_ptr, nreads, 1 if on_device else 0,
+                                                     ctypes.byref(po), ctypes.byref(pu), ctypes.byref(nu)),
+                    "musc_reads_sort_unique")
+        try:
+            order = np.ctypeslib.as_array(ctypes.cast(po, ctypes.POINTER(ctypes.c_uint32)), shape=(max(nreads, 1),))[:nreads].copy()
+            ustart = np.ctypeslib.as_array(ctypes.cast(pu, ctypes.POINTER(ctypes.c_uint32)), shape=(nu.value + 1,)).copy()
+        finally:
+            self._lib.musc_free_u32(po)
+            self._lib.musc_free_u32(pu)
+        self.n_reads = int(nu.value)
+        return order, ustart
+
     def load_reads_packed(self, seqs: Sequence[bytes]) -> None:
         buf, off = concat(seqs)
         packed, mask = pack_2bit(buf, int(off[-1]))

@@ -2268,3 +2268,6 @@ int musc_gather(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hi
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- read prep (sort + collapse)
+#include "muscato_prep.hpp"
