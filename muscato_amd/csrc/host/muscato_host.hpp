@@ -987,6 +987,57 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
   return out;
 }
 
+// The same contract with the sort and the collapse on the GPU (musc_reads_sort_unique): the
+// host parses and prepares the reads, the device orders the sequences bytewise and groups the
+// identical ones, the host orders each group's names (= comparing the whole `seq\tname` line)
+// and joins them.  MUSC_HOST_PREP=1 keeps everything on the host (cross-check).
+inline std::vector<UniqueRead> prep_reads_gpu(const std::string& fastq, const Config& c, size_t* n_total) {
+  if (const char* hp = getenv("MUSC_HOST_PREP")) if (atoi(hp) > 0) return prep_reads(fastq, c, n_total);
+  const std::vector<std::string> lines = split_lines(fastq);
+  std::vector<std::string> seqs, names;
+  for (size_t i = 0; i + 4 <= lines.size(); i += 4) {  // as in prep_reads
+    std::string seq = lines[i + 1];
+    if ((int)seq.size() < c.MinReadLength) continue;
+    subx(seq);
+    if ((int)seq.size() > c.MaxReadLength) seq.resize(c.MaxReadLength);
+    std::string rn = lines[i];
+    if (rn.size() > 1000) rn = rn.substr(0, 995) + "...";
+    seqs.push_back(std::move(seq));
+    names.push_back(std::move(rn));
+  }
+  if (n_total) *n_total = seqs.size();
+  std::vector<UniqueRead> out;
+  if (seqs.empty()) return out;
+  const Concat rd = concat(seqs.begin(), seqs.end(), [](const std::string& s) -> const std::string& { return s; });
+  musc_ctx* ctx = nullptr;
+  if (musc_init(c.Device, &ctx)) throw Die(1, std::string("read prep: ") + musc_last_error(nullptr));
+  uint32_t *order = nullptr, *ustart = nullptr;
+  uint64_t nu = 0;
+  if (musc_reads_sort_unique(ctx, rd.buf.data(), rd.off.data(), seqs.size(), 0, &order, &ustart, &nu)) {
+    const std::string e = musc_last_error(ctx);
+    musc_destroy(ctx);
+    throw Die(1, "read prep: " + e);
+  }
+  musc_destroy(ctx);
+  out.reserve(nu);
+  std::vector<const std::string*> grp;
+  for (uint64_t g = 0; g < nu; g++) {
+    grp.clear();
+    for (uint32_t k = ustart[g]; k < ustart[g + 1]; k++) grp.push_back(&names[order[k]]);
+    std::sort(grp.begin(), grp.end(), [](const std::string* a, const std::string* b) { return *a < *b; });
+    std::string na;
+    for (size_t i = 0; i < grp.size(); i++) {
+      if (i) na += ';';
+      na += grp[i]->substr(0, grp[i]->find('\t'));  // toks[1]: what follows a second tab is dropped
+    }
+    if (na.size() > 1000) na = na.substr(0, 996) + "...";  // cmd/muscato_uniqify/main.go:89-93
+    out.push_back(UniqueRead{seqs[order[ustart[g]]], grp.size(), na});
+  }
+  musc_free_u32(order);
+  musc_free_u32(ustart);
+  return out;
+}
+
 inline int run_muscato(Config cfg) {
   // setupEnvs/makeTemp/setupLog/saveConfig (cmd/muscato/main.go:906-967, 680-706)
   const std::string uid = make_uid();
@@ -1000,7 +1051,7 @@ inline int run_muscato(Config cfg) {
 
   fputs("Preparing reads...\n", stderr);
   size_t n_total = 0;
-  std::vector<UniqueRead> reads = prep_reads(slurp(cfg.ReadFileName), cfg, &n_total);
+  std::vector<UniqueRead> reads = prep_reads_gpu(slurp(cfg.ReadFileName), cfg, &n_total);
   if (reads.empty()) throw Die(1, "muscato_uniqify: no input from -");
   fprintf(stderr, "Found %zu total sequences\nFound %zu unique sequences\n", n_total, reads.size());
   spit(join_path(cfg.LogDir, "seqinfo.json"),

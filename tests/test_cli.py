@@ -227,6 +227,55 @@ def test_cli_replays_maxmatches_truncation(tmp_path, mode, seed):
     assert full != exp
 
 
+@pytest.mark.gpu
+def test_cli_read_prep_on_gpu_equals_host_prep_and_oracle(tmp_path):
+    """Duplicated reads with many names (the 1000-character cut), reads that are prefixes of
+    others, non-ACGT letters, MinReadLength / MaxReadLength: the CLI's GPU sort + collapse
+    (musc_reads_sort_unique) must give the files the host-only prep and the oracle give."""
+    import json
+    import random
+    rng = random.Random(12)
+    targets = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(40, 120))) for _ in range(12)]
+    pool = []
+    for _ in range(40):
+        t = rng.choice(targets)
+        p = rng.randint(0, len(t) - 20)
+        pool.append(t[p:p + rng.randint(8, min(60, len(t) - p))])
+    pool += [r[:len(r) // 2] for r in pool[:8]] + [b"ACNNGT" + pool[0], b"acgt" + pool[1]]
+    recs = []
+    for i in range(400):
+        r = pool[0] if i % 3 == 0 else rng.choice(pool)   # one read 130+ times: names exceed 1000 chars
+        recs.append((b"@read_%d some description %d" % (rng.randint(0, 10**6), i), r))
+    d = tmp_path
+    (d / "genes.txt").write_bytes(b"".join(b"g%d\t%s\n" % (i, t) for i, t in enumerate(targets)))
+    (d / "reads.fastq").write_bytes(b"".join(b"%s\n%s\n+\n%s\n" % (n, r, b"F" * len(r)) for n, r in recs))
+    assert run([os.path.join(BIN, "muscato_prep_targets"), "genes.txt"], d).returncode == 0
+    cfg = {"ReadFileName": "reads.fastq", "GeneFileName": "musc_genes.txt.sz", "GeneIdFileName": "musc_ids_genes.txt.sz",
+           "ResultsFileName": "result.txt", "Windows": [0, 4], "WindowWidth": 6, "PMatch": 0.9, "MinDinuc": 2,
+           "MinReadLength": 10, "MaxReadLength": 50, "MaxMatches": 100000, "MMTol": 1, "MatchMode": "best"}
+    (d / "config.json").write_text(json.dumps(cfg))
+    outs = {}
+    for mode in ("gpu", "host"):
+        env = dict(os.environ)
+        if mode == "host":
+            env["MUSC_HOST_PREP"] = "1"
+        r = run([os.path.join(BIN, "muscato"), "-ConfigFileName=config.json", "--NoCleanTemp"], d, env=env)
+        assert r.returncode == 0, r.stderr.decode()
+        tmps = sorted((d / "muscato_tmp").iterdir(), key=lambda q: q.stat().st_mtime)
+        outs[mode] = ((d / "result.txt").read_bytes(), (d / "result.nonmatch.txt.fastq").read_bytes(),
+                      orc.snappy_framed_decode((tmps[-1] / "reads_sorted.txt.sz").read_bytes()))
+    assert outs["gpu"] == outs["host"]
+    ocfg = orc.Config(Windows=[0, 4], WindowWidth=6, PMatch=0.9, MinDinuc=2, MinReadLength=10, MaxReadLength=50,
+                      MaxMatches=100000, MMTol=1, MatchMode="best")
+    ureads = orc.uniqify(orc.prep_reads(orc.read_fastq((d / "reads.fastq").read_bytes()), ocfg))
+    exp_sorted = b"".join(b"%s\t%d\t%s\n" % (u.seq, u.count, u.names) for u in ureads)
+    assert outs["gpu"][2] == exp_sorted
+    assert any(u.names.endswith(b"...") for u in ureads)   # the 1000-character rule was exercised
+    seqs, ids = orc.prep_targets_file(str(d / "genes.txt"), False)
+    hits = orc.best_filter(orc.match_direct([u.seq for u in ureads], seqs, ocfg), ocfg.MMTol)
+    assert outs["gpu"][0] == orc.results_text(hits, ureads, seqs, ids, ocfg)
+
+
 def test_cli_without_gpu_fails_loudly(golden_dir, tmp_path):
     """No GPU -> non-zero exit and a clear message, never a silent CPU path."""
     import ctypes
