@@ -10,8 +10,10 @@
 // stream plus a k-mer -> (gene, offset) table of 64-byte buckets built once per (database,
 // WindowWidth); reads are fixed-stride 2-bit records.  One pass = k_screen (window keys probe
 // the table, candidates filtered from the index entry alone) -> k_confirm (XOR/popcount Hamming
-// distance, HBM-bound) -> k_select -> scan -> k_emit (per-read best + MMTol, tuples in read
-// order).  The Bloom sketch of the reference only prunes work and cannot change results
+// distance, then per-read best + MMTol and MaxMatches accounting in the same workgroup; bound by
+// the cache lines it gathers) -> tile scan -> k_compact (tuples in read order).  Read prep
+// (bytewise sort + collapse, muscato_prep.hpp) is a separate entry point.  The Bloom sketch of
+// the reference only prunes work and cannot change results
 // (SURVEY.md 8a note H): every candidate is verified exactly in k_confirm, including its
 // window key.
 //
@@ -559,31 +561,33 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 
 #define TILE 256  // reads per tile = threads per workgroup of k_screen
 
-// k_screen -- muscato_screen + the join, fused: one workgroup per tile of 256 reads, one
-// thread per read.  For each window of the read that takes part
-// (cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185: long enough,
-// CountDinuc >= MinDinuc) the thread probes the window's index bucket and walks its entries
-// (three arrive with the probe).  From the entry alone it applies p = jx - q1 >= 0, the fit
-// rules of cmd/muscato_screen/main.go:294-316 (target position 0: the literal 100) and
-// :335-363 + cmd/muscato_confirm/main.go:201-203 (the read must end inside the target), and a
-// flank pre-filter: a candidate whose 8+8 flanking bases already disagree with the read in
-// more places than the read's whole mismatch budget can never be accepted by cdiff
+// k_screen -- muscato_screen + the join, fused: one workgroup iteration per tile of 256 reads.
+// For each window of a read that takes part (cmd/muscato_window_reads/main.go:106-118 ==
+// cmd/muscato_screen/main.go:174-185: long enough, CountDinuc >= MinDinuc) the window's index
+// bucket is fetched and its entries are tested (three arrive with the bucket, the rest sit in
+// the overflow array).  From the entry alone: p = jx - q1 >= 0, the fit rules of
+// cmd/muscato_screen/main.go:294-316 (target position 0: the literal 100) and :335-363 +
+// cmd/muscato_confirm/main.go:201-203 (the read must end inside the target), and a flank
+// pre-filter: a candidate whose 8+8 flanking bases already disagree with the read in more
+// places than the read's whole mismatch budget can never be accepted by cdiff
 // (cmd/muscato_confirm/main.go:205-211) and is dropped before it costs a target gather (chance
 // k-mer hits are about half of all candidates).  The flank test never over-counts: an X is
-// stored as code 0 on both sides.
+// stored as code 0 on both sides.  The phases are described inside the kernel.
 //
-// Survivors are appended (LDS counter) to the tile's range inside the workgroup's own region
-// of `desc` (region = desc_cap / gridDim descriptors, so no global cursor is needed).  A tile's
-// pairs are contiguous and roughly in (read, window) order, which keeps k_confirm's record
-// loads local; nothing downstream needs more than that (k_select / k_emit work per tile in LDS
-// and k_emit orders the tuples by read).
+// Survivors are appended (one LDS atomic per wave instruction) to the tile's range inside the
+// workgroup's own region of `desc` (region = desc_cap / gridDim descriptors, so no global
+// cursor is needed).  A tile's descriptors are contiguous and in (read, window) order up to
+// interleaving of the four waves, which keeps k_confirm's record loads local; nothing
+// downstream needs more than that (k_confirm keeps per-read state in LDS and orders the tuples).
 //
 // Descriptor (16 B): x = read index within the batch (24 bits) | bits 32-39 of the placement's
-// global offset << 24, y = its low 32 bits, z = window | z-flag << 4 | pos_ok << 5 | position
-// in the target << 6 (when it fits 16 bits exactly), w = gene.
+// global offset << 24, y = its low 32 bits, z = window k | z-flag << 4 | pos_ok << 5 | position
+// in the target << 6 (when it fits 16 bits exactly) | DESC_TWO (windows k and k+1 both found
+// the placement), w = gene.
 // counters (batch-local block = pass-level block + 8): [0] valid windows, [3] candidates (index
-//           entries walked), [4] descriptors, [5] descriptors that stand for two windows, [7] the largest number of descriptors any workgroup
-//           needed (region size to retry with); pass-level [3] is raised when a region ran out.
+//           entries walked), [4] descriptors, [5] descriptors that stand for two windows, [7] the
+//           largest number of descriptors any workgroup needed (region size to retry with);
+//           pass-level [3] is raised when a region ran out.
 #define SCR_OWN 2048  // overflow items per chunk whose owner is looked up directly
 #define SCR_PROBES (2 * TILE)  // probes per chunk: two windows of every read of the tile
 
@@ -1919,7 +1923,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   }
 
   HIPCHK(c, hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
-  // MaxMatches accounting (see k_best_count): screening first, exact only if inconclusive
+  // MaxMatches accounting (see k_confirm): screening first, exact only if inconclusive
   const uint64_t planned_batches = (c->nreads + c->batch_reads - 1) / c->batch_reads + 1;
   uint64_t max_matches = P->max_matches > 0 ? (uint64_t)P->max_matches : 0x7FFFFFFFull;
   if (P->n_shards > 1) max_matches /= (uint64_t)P->n_shards;  // this context sees one shard of each block
