@@ -23,6 +23,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_set>
 #include <vector>
@@ -443,6 +444,34 @@ inline void prep_targets_file(const std::string& path, bool rev, std::string* se
   spit(*id_out, sz_encode(b));
 }
 
+// Views into a text: the same line and field rules as split_lines / fields, without copies (the
+// side outputs walk results.txt three times; at a million lines the copies were most of a run).
+template <class F>
+inline void for_each_line(const std::string& s, F f) {
+  size_t pos = 0;
+  while (pos < s.size()) {
+    const size_t e = s.find('\n', pos);
+    const size_t end = e == std::string::npos ? s.size() : e;
+    size_t len = end - pos;
+    if (len && s[pos + len - 1] == '\r') len--;
+    f(std::string_view(s.data() + pos, len));
+    if (e == std::string::npos) break;
+    pos = e + 1;
+  }
+}
+
+inline int fields_sv(std::string_view s, std::string_view* out, int maxf) {  // bytes.Fields, first maxf
+  int n = 0;
+  size_t i = 0;
+  while (i < s.size() && n < maxf) {
+    while (i < s.size() && isspace((unsigned char)s[i])) i++;
+    const size_t b = i;
+    while (i < s.size() && !isspace((unsigned char)s[i])) i++;
+    if (i > b) out[n++] = s.substr(b, i - b);
+  }
+  return n;
+}
+
 // ------------------------------------------------------------------------------------
 // read preparation: utils/fastq.go, cmd/muscato_prep_reads, `sort`, cmd/muscato_uniqify
 // ------------------------------------------------------------------------------------
@@ -575,14 +604,14 @@ inline std::string nonmatch_name(const std::string& results) {  // cmd/muscato_n
 
 // cmd/muscato_nonmatch/main.go:95-114 with an exact set in place of the Bloom filter
 inline std::string nonmatch_text(const std::string& results, const std::vector<UniqueRead>& reads) {
-  std::unordered_set<std::string> matched;
-  for (auto& line : split_lines(results)) {
-    auto f = fields(line);
-    if (!f.empty()) matched.insert(f[0]);
-  }
+  std::unordered_set<std::string_view> matched;
+  for_each_line(results, [&](std::string_view line) {
+    std::string_view f[1];
+    if (fields_sv(line, f, 1)) matched.insert(f[0]);
+  });
   std::string out;
   for (auto& u : reads) {
-    if (matched.count(u.seq)) continue;
+    if (matched.count(std::string_view(u.seq))) continue;
     auto f = fields(u.seq + "\t" + std::to_string(u.count) + "\t" + u.names);
     if (f.size() < 3) continue;  // the reference would panic on an empty name
     out += f[2] + "#" + f[1] + "\n" + f[0] + "\n+\n" + std::string(f[0].size(), '!') + "\n";
@@ -600,52 +629,62 @@ inline std::string stats_name(const std::string& results, const char* tag) {  //
 
 // cmd/muscato/main.go:94-150 + cmd/muscato_genestats/main.go: sort -k5, count runs of column 5
 inline std::string genestats_text(const std::string& results) {
-  std::vector<std::string> lines = split_lines(results);
-  auto key5 = [](const std::string& l) {  // GNU sort -k5: from the blank before field 5 to the end
+  struct Ln {
+    std::string_view line, key;  // key: GNU sort -k5 = from the blank before field 5 to the end
+  };
+  std::vector<Ln> lines;
+  for_each_line(results, [&](std::string_view l) {
     size_t p = 0;
     for (int f = 0; f < 4; f++) {
       while (p < l.size() && (l[p] == ' ' || l[p] == '\t')) p++;
       while (p < l.size() && l[p] != ' ' && l[p] != '\t') p++;
     }
-    return l.substr(p);
-  };
-  std::sort(lines.begin(), lines.end(), [&](const std::string& a, const std::string& b) {
-    const std::string ka = key5(a), kb = key5(b);
-    if (ka != kb) return ka < kb;
-    return a < b;
+    lines.push_back(Ln{l, l.substr(p)});
   });
-  std::string out, old;
+  std::sort(lines.begin(), lines.end(), [](const Ln& a, const Ln& b) {
+    const int c = a.key.compare(b.key);
+    if (c) return c < 0;
+    return a.line < b.line;
+  });
+  std::string out;
+  std::string_view old;
   size_t n = 0;
   bool first = true;
+  auto flush = [&]() {
+    out.append(old.data(), old.size());
+    out += "\t" + std::to_string(n) + "\t\n";
+  };
   for (auto& l : lines) {
-    auto f = fields(l);
-    if (f.size() < 5) continue;
+    std::string_view f[5];
+    if (fields_sv(l.line, f, 5) < 5) continue;
     if (first) { old = f[4]; first = false; }
-    if (f[4] != old) { out += old + "\t" + std::to_string(n) + "\t\n"; old = f[4]; n = 0; }
+    if (f[4] != old) { flush(); old = f[4]; n = 0; }
     n++;
   }
-  if (!first) out += old + "\t" + std::to_string(n) + "\t\n";
+  if (!first) flush();
   return out;
 }
 
 // cmd/muscato_readstats/main.go: per run of equal names-column tokens, the set of gene names.
 // The reference prints the set in Go map order (random); here it is sorted.
 inline std::string readstats_text(const std::string& results) {
-  std::string out, old;
-  std::set<std::string> genes;
+  std::string out;
+  std::string_view old;
+  std::set<std::string_view> genes;
   bool first = true;
   auto flush = [&]() {
-    out += old + "\t";
-    for (auto& g : genes) out += g + ";";
-    out += "\n";
+    out.append(old.data(), old.size());
+    out += '\t';
+    for (auto& g : genes) { out.append(g.data(), g.size()); out += ';'; }
+    out += '\n';
   };
-  for (auto& l : split_lines(results)) {
-    auto f = fields(l);
-    if (f.size() < 8) continue;
+  for_each_line(results, [&](std::string_view l) {
+    std::string_view f[8];
+    if (fields_sv(l, f, 8) < 8) return;
     if (first) { old = f[7]; first = false; }
     if (f[7] != old) { flush(); old = f[7]; genes.clear(); }
     genes.insert(f[4]);
-  }
+  });
   if (!first) flush();
   return out;
 }
@@ -694,6 +733,23 @@ struct Logger {
     fflush(f);
   }
   ~Logger() { if (f) fclose(f); }
+};
+
+// wall time of the stages of a run, written to muscato.log (where the time goes end to end)
+struct StageClock {
+  Logger& log;
+  double t0, last;
+  static double now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+  }
+  explicit StageClock(Logger& l) : log(l), t0(now()), last(t0) {}
+  void lap(const char* what) {
+    const double t = now();
+    log.printf("stage %-28s %8.3f s (total %.3f s)", what, t - last, t - t0);
+    last = t;
+  }
 };
 
 inline musc_params to_params(const Config& c) {
@@ -993,17 +1049,23 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
 // and joins them.  MUSC_HOST_PREP=1 keeps everything on the host (cross-check).
 inline std::vector<UniqueRead> prep_reads_gpu(const std::string& fastq, const Config& c, size_t* n_total) {
   if (const char* hp = getenv("MUSC_HOST_PREP")) if (atoi(hp) > 0) return prep_reads(fastq, c, n_total);
-  const std::vector<std::string> lines = split_lines(fastq);
   std::vector<std::string> seqs, names;
-  for (size_t i = 0; i + 4 <= lines.size(); i += 4) {  // as in prep_reads
-    std::string seq = lines[i + 1];
-    if ((int)seq.size() < c.MinReadLength) continue;
-    subx(seq);
-    if ((int)seq.size() > c.MaxReadLength) seq.resize(c.MaxReadLength);
-    std::string rn = lines[i];
-    if (rn.size() > 1000) rn = rn.substr(0, 995) + "...";
-    seqs.push_back(std::move(seq));
-    names.push_back(std::move(rn));
+  {  // utils/fastq.go:35-61 as in prep_reads: records of four lines, an incomplete last one is dropped
+    std::string_view rec[4];
+    int k = 0;
+    for_each_line(fastq, [&](std::string_view line) {
+      rec[k++] = line;
+      if (k < 4) return;
+      k = 0;
+      if ((int)rec[1].size() < c.MinReadLength) return;
+      std::string seq(rec[1]);
+      subx(seq);
+      if ((int)seq.size() > c.MaxReadLength) seq.resize(c.MaxReadLength);
+      std::string rn(rec[0]);
+      if (rn.size() > 1000) rn = rn.substr(0, 995) + "...";
+      seqs.push_back(std::move(seq));
+      names.push_back(std::move(rn));
+    });
   }
   if (n_total) *n_total = seqs.size();
   std::vector<UniqueRead> out;
@@ -1049,6 +1111,7 @@ inline int run_muscato(Config cfg) {
   log.open(join_path(cfg.LogDir, "muscato.log"));
   spit(join_path(cfg.LogDir, "config.json"), config_to_json(cfg));
 
+  StageClock clk(log);
   fputs("Preparing reads...\n", stderr);
   size_t n_total = 0;
   std::vector<UniqueRead> reads = prep_reads_gpu(slurp(cfg.ReadFileName), cfg, &n_total);
@@ -1062,6 +1125,7 @@ inline int run_muscato(Config cfg) {
     spit(join_path(cfg.TempDir, "reads_sorted.txt.sz"), sz_encode(t));
   }
 
+  clk.lap("read prep");
   fputs("Windowing reads...\n", stderr);
   for (size_t k = 0; k < cfg.Windows.size(); k++) {  // cmd/muscato_window_reads/main.go:143-151
     size_t nvalid = 0;
@@ -1081,6 +1145,7 @@ inline int run_muscato(Config cfg) {
     id_rest.emplace(strtoull(l.substr(0, t).c_str(), nullptr, 10), l.substr(t + 1));
   }
 
+  clk.lap("windows check, target files");
   fputs("Screening...\nConfirming...\n", stderr);
   musc_stats st;
   memset(&st, 0, sizeof st);
@@ -1089,17 +1154,28 @@ inline int run_muscato(Config cfg) {
     fprintf(stderr, "Warning: %llu window-key blocks may exceed MaxMatches; results keep all their matches\n",
             (unsigned long long)st.n_overflow_blocks);
 
+  clk.lap("hot path (init, load, match)");
   fputs("Combining windows...\nJoining gene names...\nJoining read names...\n", stderr);
   const std::string res = results_text(hits.data(), hits.size(), reads, targets, id_rest);
   spit(cfg.ResultsFileName, res);
+  clk.lap("results.txt");
 
-  fputs("Writing non-matching sequences...\n", stderr);
-  spit(nonmatch_name(cfg.ResultsFileName), nonmatch_text(res, reads));
-  fputs("Generating read statistics...\n", stderr);
-  spit(stats_name(cfg.ResultsFileName, "_readstats"), readstats_text(res));
-  fputs("Generating gene statistics...\n", stderr);
-  spit(stats_name(cfg.ResultsFileName, "_genestats"), genestats_text(res));
-
+  // the three side outputs only read `res`: one thread each
+  fputs("Writing non-matching sequences...\nGenerating read statistics...\nGenerating gene statistics...\n", stderr);
+  {
+    std::string err_side[3];
+    auto guarded = [&](int i, auto fn) {
+      return std::thread([&, i, fn] {
+        try { fn(); } catch (const std::exception& e) { err_side[i] = e.what(); } catch (...) { err_side[i] = "failed"; }
+      });
+    };
+    std::thread t0 = guarded(0, [&] { spit(nonmatch_name(cfg.ResultsFileName), nonmatch_text(res, reads)); });
+    std::thread t1 = guarded(1, [&] { spit(stats_name(cfg.ResultsFileName, "_readstats"), readstats_text(res)); });
+    std::thread t2 = guarded(2, [&] { spit(stats_name(cfg.ResultsFileName, "_genestats"), genestats_text(res)); });
+    t0.join(); t1.join(); t2.join();
+    for (auto& e : err_side) if (!e.empty()) throw Die(1, "side output: " + e);
+  }
+  clk.lap("nonmatch + stats files");
   if (!cfg.NoCleanTemp) {  // cleanTmp (cmd/muscato/main.go:969-979)
     unlink(join_path(cfg.TempDir, "reads_sorted.txt.sz").c_str());
     rmdir(cfg.TempDir.c_str());

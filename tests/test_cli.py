@@ -121,10 +121,59 @@ def _stage_case(golden_dir, tmp_path, case, rev):
     return d
 
 
+def _sort_k5_key(line: bytes) -> bytes:
+    """GNU `sort -k5` under LC_ALL=C: the key runs from the blank that precedes field 5 to the
+    end of the line (fields are separated by the empty string between a non-blank and a blank)."""
+    p = 0
+    for _ in range(4):
+        while p < len(line) and line[p:p + 1] in (b" ", b"\t"):
+            p += 1
+        while p < len(line) and line[p:p + 1] not in (b" ", b"\t"):
+            p += 1
+    return line[p:]
+
+
+def expected_genestats(results: bytes) -> bytes:
+    """cmd/muscato/main.go:94-150 (`sort -k5` piped into muscato_genestats) +
+    cmd/muscato_genestats/main.go: runs of equal fifth fields, `gene\\tcount\\t`."""
+    lines = sorted(results.splitlines(), key=lambda l: (_sort_k5_key(l), l))
+    out, old, n = [], None, 0
+    for l in lines:
+        g = l.split()[4]
+        if old is not None and g != old:
+            out.append(old + b"\t%d\t\n" % n)
+            n = 0
+        old = g
+        n += 1
+    if old is not None:
+        out.append(old + b"\t%d\t\n" % n)
+    return b"".join(out)
+
+
+def expected_readstats(results: bytes) -> bytes:
+    """cmd/muscato_readstats/main.go: per run of equal eighth fields the set of fifth fields
+    (the reference prints it in Go map order; the CLI sorts it)."""
+    out, old, genes = [], None, set()
+    for l in results.splitlines():
+        f = l.split()
+        if len(f) < 8:
+            continue
+        if old is not None and f[7] != old:
+            out.append(old + b"\t" + b"".join(g + b";" for g in sorted(genes)) + b"\n")
+            genes = set()
+        old = f[7]
+        genes.add(f[4])
+    if old is not None:
+        out.append(old + b"\t" + b"".join(g + b";" for g in sorted(genes)) + b"\n")
+    return b"".join(out)
+
+
 def _check_outputs(d):
     assert (d / "result.txt").read_bytes() == (d / "result_e.txt").read_bytes()
     assert (d / "result.nonmatch.txt.fastq").read_bytes() == (d / "result.nonmatch_e.txt").read_bytes()
-    assert (d / "result_genestats.txt").exists() and (d / "result_readstats.txt").exists()
+    res = (d / "result.txt").read_bytes()
+    assert (d / "result_genestats.txt").read_bytes() == expected_genestats(res)
+    assert (d / "result_readstats.txt").read_bytes() == expected_readstats(res)
 
 
 MUSCATO_CASES = [("00", False), ("01", False), ("02", False), ("03", False), ("04", True)]
@@ -265,6 +314,8 @@ def test_cli_read_prep_on_gpu_equals_host_prep_and_oracle(tmp_path):
         outs[mode] = ((d / "result.txt").read_bytes(), (d / "result.nonmatch.txt.fastq").read_bytes(),
                       orc.snappy_framed_decode((tmps[-1] / "reads_sorted.txt.sz").read_bytes()))
     assert outs["gpu"] == outs["host"]
+    assert (d / "result_genestats.txt").read_bytes() == expected_genestats(outs["gpu"][0])
+    assert (d / "result_readstats.txt").read_bytes() == expected_readstats(outs["gpu"][0])
     ocfg = orc.Config(Windows=[0, 4], WindowWidth=6, PMatch=0.9, MinDinuc=2, MinReadLength=10, MaxReadLength=50,
                       MaxMatches=100000, MMTol=1, MatchMode="best")
     ureads = orc.uniqify(orc.prep_reads(orc.read_fastq((d / "reads.fastq").read_bytes()), ocfg))
