@@ -207,6 +207,36 @@ def test_medium_synthetic_against_literal_oracle(eng, xrate):
     assert st["n_reads"] == len(reads)
 
 
+MEDIUM_MATRIX = [
+    # windows, ww, pmatch, mindinuc, mmtol, xrate, n_targets, n_reads
+    ((0, 20, 40), 15, 0.97, 3, 3, 0.0, 20000, 200000),      # BASELINE configs[4] shape: odd window count
+    ((0, 20, 40), 15, 0.95, 5, 1, 0.002, 8000, 120000),     # the same with X on both sides (mask planes)
+    ((0, 30), 17, 0.96, 0, 0, 0.0, 8000, 120000),           # 17-mers: hashed index (34-bit keys)
+    ((5, 25, 45, 65), 12, 0.94, 1, 2, 0.001, 4000, 80000),  # four windows, none at 0, 12-mers (dense buckets)
+    ((0, 1), 15, 0.93, 0, 0, 0.0, 4000, 60000),             # overlapping windows: most placements found twice
+]
+
+
+@pytest.mark.parametrize("windows,ww,pmatch,mindinuc,mmtol,xrate,nt,nr", MEDIUM_MATRIX)
+def test_medium_matrix_against_literal_oracle(eng, windows, ww, pmatch, mindinuc, mmtol, xrate, nt, nr):
+    """Tens of thousands of reads per configuration against the reference-shaped C++ oracle:
+    both the union over windows and the best+MMTol selection, plus the MaxMatches verdict."""
+    from muscato_amd import sorted_hits
+    reads, targets = synthetic_medium(1000 + ww + len(windows), nt, nr, xrate=xrate)
+    c = orc.Config(Windows=list(windows), WindowWidth=ww, PMatch=pmatch, MinDinuc=mindinuc, MaxReadLength=100,
+                   MaxMatches=1000000, MMTol=mmtol)
+    rbuf, roff = literal.concat(reads)
+    gbuf, goff = literal.concat(targets)
+    exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff,
+                                     literal.make_params(c, bloom_size=256_000_000, num_hash=8, nthreads=8))
+    got = gpu_hits(eng, c, reads, targets, False)
+    assert len(got) > nr // 4
+    assert_same(got, exp)
+    assert eng.stats()["n_overflow_blocks"] == 0
+    best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
+    assert_same(best, as_arr(orc.best_filter([tuple(int(x) for x in r) for r in exp], mmtol)))
+
+
 def test_stats_and_repeat_calls_are_stable(eng):
     from muscato_amd import sorted_hits
     ocfg, reads, targets = make_case(4)
