@@ -225,15 +225,24 @@ def main() -> int:
         from muscato_amd.dist import HitGatherer
         n0 = eng.match_device(cfg, apply_mmtol=True, skip_block_check=args.no_block_check)
         gdev = device if backend == "nccl" else torch.device("cpu")
-        gatherer = HitGatherer(HitGatherer.agree_capacity(n0, gdev), gdev)
+        # 8-byte tuples on the links when the fields fit 64 bits: global read number, target
+        # number, position, mismatch count (rank 0 ingests 7 shards' tuples per pass at 8 GPUs)
+        budget = int((1.0 - wl.pmatch) * wl.read_len)
+        pack_bits = [max(1, (world * U - 1).bit_length()), max(1, (wl.n_targets - 1).bit_length()),
+                     max(1, wl.target_len.bit_length()), max(1, budget.bit_length())]
+        use_packed = sum(pack_bits) <= 64 and not os.environ.get("MUSC_BENCH_UNPACKED")
+        gatherer = HitGatherer(HitGatherer.agree_capacity(n0, gdev), gdev, packed=use_packed)
 
-    gather_mode = ["overlapped (HitGatherer)" if world > 1 else "none"]
+    gather_mode = ["none" if world == 1 else
+                   "overlapped (HitGatherer), " + ("8-byte packed tuples %s" % pack_bits if use_packed else "16-byte tuples")]
 
     def step():
         n = eng.match_device(cfg, apply_mmtol=True, skip_block_check=args.no_block_check)
         if world > 1 and gather_mode[0].startswith("overlapped"):
             def fill(buf):
-                if n:
+                if n and gatherer.packed:
+                    eng.hits_to_packed(buf.data_ptr(), n, buf.is_cuda, pack_bits, read_base)
+                elif n:
                     eng.hits_to(buf.data_ptr(), n, buf.is_cuda)
                 return n
             try:

@@ -167,6 +167,16 @@ int musc_reads_sort_unique(musc_ctx* ctx, const char* seqs, const uint64_t* offs
  * hits; musc_match = both, into a library-owned host array.  Hit order is unspecified. */
 int musc_match_device(musc_ctx* ctx, const musc_params* params, uint64_t* nhits);
 int musc_hits_copy(musc_ctx* ctx, musc_hit* dst, uint64_t capacity, int dst_on_device);
+/* The same tuples as one u64 each, for the wire (gather to rank 0 over RCCL/xGMI) or for keeping
+ * them compact: (read_idx + read_base) in the top bits, then gene_idx, pos, nmiss, with
+ * bits[4] = the widths of read, gene, pos, nmiss (each 1..32, sum <= 64).  The numeric order of
+ * the words is the lexicographic order of the tuples.  Fails with code 8 if a field of some
+ * tuple does not fit its width.  musc_hits_unpack inverts it (src and dst both on the device or
+ * both on the host). */
+int musc_hits_copy_packed(musc_ctx* ctx, uint64_t* dst, uint64_t capacity, int dst_on_device,
+                          uint64_t read_base, const int32_t* bits);
+int musc_hits_unpack(musc_ctx* ctx, const uint64_t* src, uint64_t n, int on_device, const int32_t* bits,
+                     musc_hit* dst);
 int musc_match(musc_ctx* ctx, const musc_params* params, musc_hit** hits, uint64_t* nhits);
 void musc_free_hits(musc_hit* hits);
 

@@ -54,7 +54,7 @@ SYMBOLS = [
     "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error",
     "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
     "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique",
-    "musc_match_device", "musc_hits_copy", "musc_match", "musc_free_hits",
+    "musc_match_device", "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_unpack", "musc_match", "musc_free_hits",
     "musc_get_stats", "musc_gather", "musc_overflow_probes", "musc_free_u32",
 ]
 
@@ -90,6 +90,8 @@ def load() -> ctypes.CDLL:
                                            ctypes.POINTER(u64)]
     lib.musc_match_device.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(u64)]
     lib.musc_hits_copy.argtypes = [vp, vp, u64, ctypes.c_int]
+    lib.musc_hits_copy_packed.argtypes = [vp, vp, u64, ctypes.c_int, u64, ctypes.POINTER(i32)]
+    lib.musc_hits_unpack.argtypes = [vp, vp, u64, ctypes.c_int, ctypes.POINTER(i32), vp]
     lib.musc_match.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.musc_free_hits.argtypes = [vp]
     lib.musc_free_hits.restype = None
@@ -102,7 +104,8 @@ def load() -> ctypes.CDLL:
                                 ctypes.POINTER(vp), ctypes.POINTER(u64)]
     for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
                  "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique", "musc_match_device",
-                 "musc_hits_copy", "musc_match", "musc_get_stats", "musc_gather"):
+                 "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_unpack", "musc_match", "musc_get_stats",
+                 "musc_gather"):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
     return lib

@@ -255,6 +255,16 @@ class Engine:
     def hits_to(self, ptr: int, capacity: int, on_device: bool) -> None:
         self._check(self._lib.musc_hits_copy(self._h, ptr, capacity, 1 if on_device else 0), "musc_hits_copy")
 
+    def hits_to_packed(self, ptr: int, capacity: int, on_device: bool, bits: Sequence[int], read_base: int = 0) -> None:
+        """The last pass's tuples as one u64 each (read+base | gene | pos | nmiss, widths `bits`)."""
+        b = (ctypes.c_int32 * 4)(*bits)
+        self._check(self._lib.musc_hits_copy_packed(self._h, ptr, capacity, 1 if on_device else 0, read_base, b),
+                    "musc_hits_copy_packed")
+
+    def unpack_hits(self, src_ptr: int, n: int, on_device: bool, bits: Sequence[int], dst_ptr: int) -> None:
+        b = (ctypes.c_int32 * 4)(*bits)
+        self._check(self._lib.musc_hits_unpack(self._h, src_ptr, n, 1 if on_device else 0, b, dst_ptr), "musc_hits_unpack")
+
     def match(self, cfg: Config, apply_mmtol: bool = True) -> np.ndarray:
         """-> uint32 array [n, 4] of (read_idx, gene_idx, pos, nmiss), order unspecified."""
         n = self.match_device(cfg, apply_mmtol)

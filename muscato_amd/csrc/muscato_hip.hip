@@ -1209,6 +1209,38 @@ __global__ void k_block_overflow(const uint32_t* __restrict__ block_table, uint3
 
 // ------------------------------------------------------------------------------------
 // host side
+// Tuples as one u64 each for the wire (RCCL gather to rank 0): read index (+ the shard's base)
+// in the top bits, then gene, position, mismatch count with caller-chosen widths; numeric order
+// of the words = lexicographic order of the tuples.  *bad is raised if a field does not fit.
+struct PackBits {
+  int32_t read, gene, pos, nmiss;
+};
+
+__global__ __launch_bounds__(256) void k_pack_hits(const uint4* __restrict__ hits, uint64_t n, uint64_t read_base,
+                                                   PackBits b, uint64_t* __restrict__ out, uint32_t* __restrict__ bad) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 h = hits[i];
+    const uint64_t r = (uint64_t)h.x + read_base;
+    if ((b.read < 64 && (r >> b.read)) || ((uint64_t)h.y >> b.gene) || ((uint64_t)h.z >> b.pos) || ((uint64_t)h.w >> b.nmiss))
+      atomicOr(bad, 1u);
+    out[i] = (((((r << b.gene) | h.y) << b.pos) | h.z) << b.nmiss) | h.w;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_hits(const uint64_t* __restrict__ in, uint64_t n, PackBits b,
+                                                     uint4* __restrict__ hits) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t v = in[i];
+    const uint32_t nm = (uint32_t)(v & ((1ull << b.nmiss) - 1ull));
+    v >>= b.nmiss;
+    const uint32_t pos = (uint32_t)(v & ((1ull << b.pos) - 1ull));
+    v >>= b.pos;
+    const uint32_t gene = (uint32_t)(v & ((1ull << b.gene) - 1ull));
+    v >>= b.gene;
+    hits[i] = make_uint4((uint32_t)v, gene, pos, nm);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 
 namespace {
@@ -1285,6 +1317,8 @@ struct musc_ctx {
 
   DevBuf<musc_hit> hits;
   uint64_t nhits = 0;
+  DevBuf<uint64_t> packed;      // staging of musc_hits_copy_packed / musc_hits_unpack for host pointers
+  uint32_t* d_flag = nullptr;   // one device word for kernels that report "does not fit"
 
   uint32_t batch_reads = 16u << 20;
   // A pass over the same reads, database and parameters as the last completed one needs no
@@ -1573,6 +1607,8 @@ void musc_destroy(musc_ctx* c) {
   c->nmiss_tab.release();
   c->block_table.release();
   c->hits.release();
+  c->packed.release();
+  if (c->d_flag) (void)hipFree(c->d_flag);
   if (c->counters) (void)hipFree(c->counters);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   for (hipEvent_t ev : {c->ev_ready[0], c->ev_ready[1], c->ev_free[0], c->ev_free[1], c->ev_join})
@@ -2155,6 +2191,77 @@ int musc_hits_copy(musc_ctx* c, musc_hit* dst, uint64_t capacity, int dst_on_dev
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(dst, c->hits.p, c->nhits * sizeof(musc_hit),
                            dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int check_pack_bits(musc_ctx* c, const int32_t* bits, PackBits* b) {
+  if (!bits) return fail(c, 2, "bits is NULL");
+  int sum = 0;
+  for (int i = 0; i < 4; i++) {
+    if (bits[i] < 1 || bits[i] > 32) return fail(c, 2, "field width %d outside 1..32", bits[i]);
+    sum += bits[i];
+  }
+  if (sum > 64) return fail(c, 2, "field widths add up to %d > 64 bits", sum);
+  *b = PackBits{bits[0], bits[1], bits[2], bits[3]};
+  return 0;
+}
+
+int musc_hits_copy_packed(musc_ctx* c, uint64_t* dst, uint64_t capacity, int dst_on_device, uint64_t read_base,
+                          const int32_t* bits) {
+  if (!c) return 1;
+  PackBits b;
+  int rc = check_pack_bits(c, bits, &b);
+  if (rc) return rc;
+  if (capacity < c->nhits) return fail(c, 2, "musc_hits_copy_packed: capacity %llu < %llu hits",
+                                       (unsigned long long)capacity, (unsigned long long)c->nhits);
+  if (c->nhits == 0) return 0;
+  if (!dst) return fail(c, 2, "musc_hits_copy_packed: dst is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->d_flag) HIPCHK(c, hipMalloc((void**)&c->d_flag, 4));
+  uint64_t* out = dst;
+  if (!dst_on_device) {
+    if ((rc = ensure(c, c->packed, c->nhits))) return rc;
+    out = c->packed.p;
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_pack_hits, dim3(std::min(nblk(c->nhits, 256), MAX_GRID)), dim3(256), 0, c->stream,
+                     reinterpret_cast<const uint4*>(c->hits.p), c->nhits, read_base, b, out, c->d_flag);
+  HIPCHK(c, hipGetLastError());
+  uint32_t bad = 0;
+  HIPCHK(c, hipMemcpyAsync(&bad, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+  if (!dst_on_device)
+    HIPCHK(c, hipMemcpyAsync(dst, out, c->nhits * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (bad) return fail(c, 8, "musc_hits_copy_packed: a tuple field does not fit its width (%d/%d/%d/%d bits)",
+                       b.read, b.gene, b.pos, b.nmiss);
+  return 0;
+}
+
+int musc_hits_unpack(musc_ctx* c, const uint64_t* src, uint64_t n, int on_device, const int32_t* bits, musc_hit* dst) {
+  if (!c) return 1;
+  PackBits b;
+  int rc = check_pack_bits(c, bits, &b);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!src || !dst) return fail(c, 2, "musc_hits_unpack: NULL pointer");
+  if (!on_device) {  // host to host: plain loop, same layout
+    for (uint64_t i = 0; i < n; i++) {
+      uint64_t v = src[i];
+      dst[i].nmiss = (uint32_t)(v & ((1ull << b.nmiss) - 1ull));
+      v >>= b.nmiss;
+      dst[i].pos = (uint32_t)(v & ((1ull << b.pos) - 1ull));
+      v >>= b.pos;
+      dst[i].gene_idx = (uint32_t)(v & ((1ull << b.gene) - 1ull));
+      v >>= b.gene;
+      dst[i].read_idx = (uint32_t)v;
+    }
+    return 0;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_unpack_hits, dim3(std::min(nblk(n, 256), MAX_GRID)), dim3(256), 0, c->stream, src, n, b,
+                     reinterpret_cast<uint4*>(dst));
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

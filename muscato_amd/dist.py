@@ -58,21 +58,24 @@ class HitGatherer:
     pass i runs on the communicator's stream while pass i+1 is being matched.
 
     Every rank owns `depth` send buffers of `cap` + 1 rows; row `cap` carries the tuple count, so
-    no separate exchange of counts is needed.  Rank `dst` owns `depth` sets of receive buffers.
+    no separate exchange of counts is needed.  With `packed=True` a row is one int64 word (the
+    layout of musc_hits_copy_packed: half the bytes on the links; fill() must then write words
+    that already include the shard's read base), otherwise four int32 (read, gene, pos, nmiss).  Rank `dst` owns `depth` sets of receive buffers.
     submit() fills the next send buffer through `fill(buf_rows) -> n` (e.g. Engine.hits_to),
     rebases column 0 by `read_base` and starts an asynchronous gather; it first waits for the
     gather issued `depth` passes earlier, whose buffers it reuses.  finish() waits for
     everything; on `dst`, counts(k) / last_result() then give the tuples per rank -- rank-order
     concatenation is the global read order."""
 
-    def __init__(self, cap: int, device, depth: int = 2, dst: int = 0, group=None, dtype=torch.int32):
-        self.cap, self.depth, self.dst, self.group = int(cap), depth, dst, group
+    def __init__(self, cap: int, device, depth: int = 2, dst: int = 0, group=None, packed: bool = False):
+        self.cap, self.depth, self.dst, self.group, self.packed = int(cap), depth, dst, group, packed
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.send = [torch.zeros((self.cap + 1, 4), dtype=dtype, device=device) for _ in range(depth)]
+        shape, dtype = ((self.cap + 1,), torch.int64) if packed else ((self.cap + 1, 4), torch.int32)
+        self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self.recv = None
         if self.rank == dst:
-            self.recv = [[torch.empty((self.cap + 1, 4), dtype=dtype, device=device) for _ in range(self.world)]
+            self.recv = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)]
                          for _ in range(depth)]
         self.work = [None] * depth
         self.i = 0
@@ -95,9 +98,12 @@ class HitGatherer:
         n = int(fill(buf))
         if n > self.cap:
             raise RuntimeError("HitGatherer: %d hits exceed the agreed capacity %d" % (n, self.cap))
-        if read_base and n:
-            buf[:n, 0] += read_base
-        buf[self.cap, 0] = n
+        if self.packed:
+            buf[self.cap] = n
+        else:
+            if read_base and n:
+                buf[:n, 0] += read_base
+            buf[self.cap, 0] = n
         self.work[k] = dist.gather(buf, gather_list=self.recv[k] if self.rank == self.dst else None,
                                    dst=self.dst, group=self.group, async_op=True)
         self.i += 1
@@ -105,7 +111,7 @@ class HitGatherer:
 
     def counts(self, k: int) -> List[int]:
         """Tuple counts per rank of buffer set k (rank dst, after its gather completed)."""
-        return [int(b[self.cap, 0].item()) for b in self.recv[k]]
+        return [int((b[self.cap] if self.packed else b[self.cap, 0]).item()) for b in self.recv[k]]
 
     def finish(self) -> Optional[List[int]]:
         """Wait for all outstanding gathers; on dst return the per-rank counts of the last pass."""
@@ -119,8 +125,20 @@ class HitGatherer:
             return None
         return self.counts((self.i - 1) % self.depth)
 
+    @staticmethod
+    def unpack(words: torch.Tensor, bits) -> torch.Tensor:
+        """int64 words of musc_hits_copy_packed -> int64 [n, 4] (read, gene, pos, nmiss)."""
+        br, bg, bp, bn = bits
+        w = words.to(torch.int64)
+        nm = w & ((1 << bn) - 1)
+        pos = (w >> bn) & ((1 << bp) - 1)
+        gene = (w >> (bn + bp)) & ((1 << bg) - 1)
+        read = (w >> (bn + bp + bg)) & ((1 << br) - 1)   # the mask also undoes the sign extension of bit 63
+        return torch.stack([read, gene, pos, nm], dim=1)
+
     def last_result(self) -> Optional[torch.Tensor]:
-        """After finish(): the last pass's tuples on dst, concatenated in rank order."""
+        """After finish(): the last pass's tuples on dst, concatenated in rank order (int64 words
+        when packed -- see unpack())."""
         if self.rank != self.dst or self.i == 0:
             return None
         k = (self.i - 1) % self.depth

@@ -140,3 +140,41 @@ def test_streaming_gatherer_two_ranks(tmp_path):
             exp.append(t)
         assert cn == [len(e) for e in exp]
         assert torch.equal(res, torch.cat(exp))
+
+
+def _packed_worker(rank, world, port, outdir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from muscato_amd.dist import HitGatherer
+    bits = (20, 12, 10, 3)
+    g = HitGatherer(64, torch.device("cpu"), depth=2, packed=True)
+    for p in range(3):
+        n = 7 + rank + p
+        t = torch.stack([torch.arange(n) + 1000 * rank, torch.arange(n) * 3 % 4096, torch.arange(n) * 7 % 1024,
+                         torch.arange(n) % 8], dim=1).to(torch.int64)
+        words = (((t[:, 0] << bits[1] | t[:, 1]) << bits[2] | t[:, 2]) << bits[3]) | t[:, 3]
+
+        def fill(buf, words=words):
+            buf[:len(words)] = words
+            return len(words)
+        g.submit(fill, read_base=0)
+    cn = g.finish()
+    if rank == 0:
+        torch.save((cn, HitGatherer.unpack(g.last_result(), bits)), os.path.join(outdir, "packed.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_streaming_gatherer_packed_words(tmp_path):
+    mp.spawn(_packed_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    cn, res = torch.load(tmp_path / "packed.pt")
+    exp = []
+    for rank in range(2):
+        n = 7 + rank + 2
+        exp.append(torch.stack([torch.arange(n) + 1000 * rank, torch.arange(n) * 3 % 4096, torch.arange(n) * 7 % 1024,
+                                torch.arange(n) % 8], dim=1).to(torch.int64))
+    assert cn == [len(e) for e in exp]
+    assert torch.equal(res, torch.cat(exp))

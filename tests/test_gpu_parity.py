@@ -237,6 +237,54 @@ def test_medium_matrix_against_literal_oracle(eng, windows, ww, pmatch, mindinuc
     assert_same(best, as_arr(orc.best_filter([tuple(int(x) for x in r) for r in exp], mmtol)))
 
 
+def test_packed_tuples_roundtrip(eng):
+    """musc_hits_copy_packed / musc_hits_unpack: 8-byte words whose numeric order is the tuple
+    order, exact round trip, and a loud failure when a field does not fit its width."""
+    import ctypes
+    from muscato_amd import sorted_hits
+    ocfg, reads, targets = make_case(77)
+    exp = gpu_hits(eng, ocfg, reads, targets, False)
+    n = len(exp)
+    assert n > 10
+    bits = [max(1, (len(reads) + 999).bit_length()), max(1, len(targets).bit_length()),
+            max(1, max(len(t) for t in targets).bit_length()), 8]
+    words = np.zeros(n, dtype=np.uint64)
+    eng.hits_to_packed(words.ctypes.data, n, False, bits, read_base=1000)
+    back = np.zeros((n, 4), dtype=np.uint32)
+    eng.unpack_hits(words.ctypes.data, n, False, bits, back.ctypes.data)
+    back[:, 0] -= 1000
+    assert (sorted_hits(back) == exp).all()
+    # numeric order of the words == lexicographic order of the tuples
+    order = np.argsort(words, kind="stable")
+    assert (back[order] == exp).all()
+    # numpy view of the layout
+    w = words.astype(np.uint64)
+    assert ((w & np.uint64(255)) == back[:, 3]).all()
+    # device destinations (what the RCCL path uses); plain HIP runtime calls, no torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    dw, dh = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dw), n * 8) == 0 and hip.hipMalloc(ctypes.byref(dh), n * 16) == 0
+    try:
+        eng.hits_to_packed(dw.value, n, True, bits, read_base=1000)
+        w2 = np.zeros(n, dtype=np.uint64)
+        assert hip.hipMemcpy(w2.ctypes.data, dw, n * 8, 2) == 0   # hipMemcpyDeviceToHost
+        assert (w2 == words).all()
+        eng.unpack_hits(dw.value, n, True, bits, dh.value)
+        h2 = np.zeros((n, 4), dtype=np.uint32)
+        assert hip.hipMemcpy(h2.ctypes.data, dh, n * 16, 2) == 0
+        assert (h2 == back + np.array([1000, 0, 0, 0], dtype=np.uint32)).all()
+    finally:
+        hip.hipFree(dw)
+        hip.hipFree(dh)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        eng.hits_to_packed(words.ctypes.data, n, False, [bits[0], bits[1], 1, 8])
+    with pytest.raises(RuntimeError, match="64 bits"):
+        eng.hits_to_packed(words.ctypes.data, n, False, [32, 32, 32, 8])
+
+
 def test_stats_and_repeat_calls_are_stable(eng):
     from muscato_amd import sorted_hits
     ocfg, reads, targets = make_case(4)
