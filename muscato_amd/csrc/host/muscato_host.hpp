@@ -481,50 +481,6 @@ struct UniqueRead {
   std::string names;
 };
 
-inline std::vector<UniqueRead> prep_reads(const std::string& fastq, const Config& c, size_t* n_total) {
-  const std::vector<std::string> lines = split_lines(fastq);
-  std::vector<std::string> recs;  // "seq\tname"
-  for (size_t i = 0; i + 4 <= lines.size(); i += 4) {
-    // utils/fastq.go:35-61: 4 lines per record, name = whole first line; an incomplete
-    // trailing record is dropped
-    const std::string& name = lines[i];
-    std::string seq = lines[i + 1];
-    if ((int)seq.size() < c.MinReadLength) continue;           // cmd/muscato_prep_reads/main.go:59-62 (raw length)
-    subx(seq);                                                 // :64-65
-    if ((int)seq.size() > c.MaxReadLength) seq.resize(c.MaxReadLength);  // :67-69
-    std::string rn = name;
-    if (rn.size() > 1000) rn = rn.substr(0, 995) + "...";      // :76-79
-    recs.push_back(seq + "\t" + rn);
-  }
-  std::sort(recs.begin(), recs.end());  // LC_ALL=C sort of whole lines (cmd/muscato/main.go:180-189)
-  if (n_total) *n_total = recs.size();
-  // cmd/muscato_uniqify/main.go:83-135
-  std::vector<UniqueRead> out;
-  std::vector<std::string> names;
-  std::string cur;
-  bool have = false;
-  auto flush = [&]() {
-    std::string na;
-    for (size_t i = 0; i < names.size(); i++) { if (i) na += ';'; na += names[i]; }
-    if (na.size() > 1000) na = na.substr(0, 996) + "...";
-    out.push_back(UniqueRead{cur, names.size(), na});
-  };
-  for (auto& r : recs) {
-    size_t t = r.find('\t');
-    std::string seq = r.substr(0, t);
-    size_t t2 = r.find('\t', t + 1);
-    std::string nm = r.substr(t + 1, t2 == std::string::npos ? std::string::npos : t2 - t - 1);
-    if (!have || seq != cur) {
-      if (have) flush();
-      cur = seq;
-      names.clear();
-      have = true;
-    }
-    names.push_back(nm);
-  }
-  if (have) flush();
-  return out;
-}
 
 // ------------------------------------------------------------------------------------
 // post-chain (cmd/muscato/main.go:422-676) and side outputs
@@ -1043,14 +999,14 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
   return out;
 }
 
-// The same contract with the sort and the collapse on the GPU (musc_reads_sort_unique): the
-// host parses and prepares the reads, the device orders the sequences bytewise and groups the
-// identical ones, the host orders each group's names (= comparing the whole `seq\tname` line)
-// and joins them.  MUSC_HOST_PREP=1 keeps everything on the host (cross-check).
-inline std::vector<UniqueRead> prep_reads_gpu(const std::string& fastq, const Config& c, size_t* n_total) {
-  if (const char* hp = getenv("MUSC_HOST_PREP")) if (atoi(hp) > 0) return prep_reads(fastq, c, n_total);
+// utils/fastq.go + cmd/muscato_prep_reads on the host (parse, MinReadLength on the raw length,
+// subx, MaxReadLength, the 1000-character name rule); the `sort` of the `seq\tname` lines and
+// cmd/muscato_uniqify/main.go:83-135 through musc_reads_sort_unique: the device orders the
+// sequences bytewise and groups the identical ones, the host orders each group's names
+// (= comparing the whole `seq\tname` line) and joins them.
+inline std::vector<UniqueRead> prep_reads(const std::string& fastq, const Config& c, size_t* n_total) {
   std::vector<std::string> seqs, names;
-  {  // utils/fastq.go:35-61 as in prep_reads: records of four lines, an incomplete last one is dropped
+  {  // utils/fastq.go:35-61: records of four lines, name = whole first line, an incomplete last one is dropped
     std::string_view rec[4];
     int k = 0;
     for_each_line(fastq, [&](std::string_view line) {
@@ -1114,7 +1070,7 @@ inline int run_muscato(Config cfg) {
   StageClock clk(log);
   fputs("Preparing reads...\n", stderr);
   size_t n_total = 0;
-  std::vector<UniqueRead> reads = prep_reads_gpu(slurp(cfg.ReadFileName), cfg, &n_total);
+  std::vector<UniqueRead> reads = prep_reads(slurp(cfg.ReadFileName), cfg, &n_total);
   if (reads.empty()) throw Die(1, "muscato_uniqify: no input from -");
   fprintf(stderr, "Found %zu total sequences\nFound %zu unique sequences\n", n_total, reads.size());
   spit(join_path(cfg.LogDir, "seqinfo.json"),

@@ -277,10 +277,10 @@ def test_cli_replays_maxmatches_truncation(tmp_path, mode, seed):
 
 
 @pytest.mark.gpu
-def test_cli_read_prep_on_gpu_equals_host_prep_and_oracle(tmp_path):
+def test_cli_read_prep_on_gpu_equals_oracle(tmp_path):
     """Duplicated reads with many names (the 1000-character cut), reads that are prefixes of
     others, non-ACGT letters, MinReadLength / MaxReadLength: the CLI's GPU sort + collapse
-    (musc_reads_sort_unique) must give the files the host-only prep and the oracle give."""
+    (musc_reads_sort_unique) must give the files the oracle gives."""
     import json
     import random
     rng = random.Random(12)
@@ -303,28 +303,22 @@ def test_cli_read_prep_on_gpu_equals_host_prep_and_oracle(tmp_path):
            "ResultsFileName": "result.txt", "Windows": [0, 4], "WindowWidth": 6, "PMatch": 0.9, "MinDinuc": 2,
            "MinReadLength": 10, "MaxReadLength": 50, "MaxMatches": 100000, "MMTol": 1, "MatchMode": "best"}
     (d / "config.json").write_text(json.dumps(cfg))
-    outs = {}
-    for mode in ("gpu", "host"):
-        env = dict(os.environ)
-        if mode == "host":
-            env["MUSC_HOST_PREP"] = "1"
-        r = run([os.path.join(BIN, "muscato"), "-ConfigFileName=config.json", "--NoCleanTemp"], d, env=env)
-        assert r.returncode == 0, r.stderr.decode()
-        tmps = sorted((d / "muscato_tmp").iterdir(), key=lambda q: q.stat().st_mtime)
-        outs[mode] = ((d / "result.txt").read_bytes(), (d / "result.nonmatch.txt.fastq").read_bytes(),
-                      orc.snappy_framed_decode((tmps[-1] / "reads_sorted.txt.sz").read_bytes()))
-    assert outs["gpu"] == outs["host"]
-    assert (d / "result_genestats.txt").read_bytes() == expected_genestats(outs["gpu"][0])
-    assert (d / "result_readstats.txt").read_bytes() == expected_readstats(outs["gpu"][0])
+    r = run([os.path.join(BIN, "muscato"), "-ConfigFileName=config.json", "--NoCleanTemp"], d)
+    assert r.returncode == 0, r.stderr.decode()
+    tmps = list((d / "muscato_tmp").iterdir())
+    out = ((d / "result.txt").read_bytes(), (d / "result.nonmatch.txt.fastq").read_bytes(),
+           orc.snappy_framed_decode((tmps[0] / "reads_sorted.txt.sz").read_bytes()))
+    assert (d / "result_genestats.txt").read_bytes() == expected_genestats(out[0])
+    assert (d / "result_readstats.txt").read_bytes() == expected_readstats(out[0])
     ocfg = orc.Config(Windows=[0, 4], WindowWidth=6, PMatch=0.9, MinDinuc=2, MinReadLength=10, MaxReadLength=50,
                       MaxMatches=100000, MMTol=1, MatchMode="best")
     ureads = orc.uniqify(orc.prep_reads(orc.read_fastq((d / "reads.fastq").read_bytes()), ocfg))
     exp_sorted = b"".join(b"%s\t%d\t%s\n" % (u.seq, u.count, u.names) for u in ureads)
-    assert outs["gpu"][2] == exp_sorted
+    assert out[2] == exp_sorted
     assert any(u.names.endswith(b"...") for u in ureads)   # the 1000-character rule was exercised
     seqs, ids = orc.prep_targets_file(str(d / "genes.txt"), False)
     hits = orc.best_filter(orc.match_direct([u.seq for u in ureads], seqs, ocfg), ocfg.MMTol)
-    assert outs["gpu"][0] == orc.results_text(hits, ureads, seqs, ids, ocfg)
+    assert out[0] == orc.results_text(hits, ureads, seqs, ids, ocfg)
 
 
 def test_cli_without_gpu_fails_loudly(golden_dir, tmp_path):
