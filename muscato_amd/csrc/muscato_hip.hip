@@ -2135,7 +2135,10 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     n_pairs = c->h_pinned[8 + 4];
     n_two = c->h_pinned[8 + 5];
   } else if (c->h_pinned[3]) {
-    return fail(c, 12, "internal: capacity guard fired on a sized pass (flags %llu)", (unsigned long long)c->h_pinned[3]);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return fail(c, 12, "internal: a capacity guard fired although every batch was sized (flags %llu)",
+                (unsigned long long)c->h_pinned[3]);
   }
   c->stats.n_read_windows = n_windows;
   c->stats.n_accepted = c->h_pinned[1];
