@@ -74,6 +74,21 @@ def cpu_baseline(wl, cfg, targets_ascii, reads_ascii, eng_factory, n_raw_full, l
     t_full = t_scan * ft + (t_win + t_bloom) * fr + (t_csort + t_conf) * fr * ft
     value = n_raw_full / t_full if t_full > 0 else 0.0
 
+    # the same port on ONE thread (SURVEY.md 8d asks for both), on a smaller sample to stay bounded
+    s1, tp1 = min(s, 100_000), min(tp, 20_000)
+    st1 = max(1, s // s1)
+    rb1 = np.concatenate([rbuf[:s * L].reshape(s, L)[::st1][:s1].reshape(-1), np.zeros(8, np.uint8)])
+    gb1 = np.concatenate([gbuf[:tp1 * TL], np.zeros(8, np.uint8)])
+    p1 = literal.make_params(OC, bloom_size=4_000_000_000, num_hash=20, nthreads=1)
+    t1 = time.time()
+    _, tim1, _ = literal.match_arrays(rb1, np.arange(s1 + 1, dtype=np.uint64) * np.uint64(L), gb1,
+                                      np.arange(tp1 + 1, dtype=np.uint64) * np.uint64(TL), p1)
+    wall1 = time.time() - t1
+    w1, b1, sc1, cs1, cf1 = [float(x) for x in tim1]
+    t_full1 = sc1 * (T / tp1) + (w1 + b1) * (U / s1) + (cs1 + cf1) * (U / s1) * (T / tp1)
+    single = {"value": n_raw_full / t_full1 if t_full1 > 0 else 0.0, "cores": 1,
+              "sample": "%d reads x %d targets, same port and extrapolation, %.1fs wall" % (s1, tp1, wall1)}
+
     # bit-exactness of the GPU path on the very same sample (all accepted tuples, no MMTol)
     from muscato_amd import sorted_hits
     eng = eng_factory()
@@ -92,6 +107,7 @@ def cpu_baseline(wl, cfg, targets_ascii, reads_ascii, eng_factory, n_raw_full, l
                    "extrapolated to the full batch as scan*%.0f + read terms*%.1f + pair terms*%.1f*%.0f = %.1fs"
                    % (s, s + s // 9, tp, T, t_scan, t_win + t_bloom, t_csort + t_conf, ft, fr, fr, ft, t_full)),
         "sample_wall_s": wall, "gpu_bit_exact_on_sample": exact, "sample_hits": int(len(exp)),
+        "single_thread": single,
     }
 
 
