@@ -442,6 +442,7 @@ struct PathParams {
   int32_t apply_mmtol;
   uint32_t q1zero_mask;  // windows whose start is 0 (the pos-0 path of processSeq)
   int32_t wide;          // database >= 2^32 bases: 40-bit positions (gene < 2^24)
+  int32_t max_len;       // longest read loaded
   int32_t dbg;           // experiments only (MUSC_DEBUG_SCREEN): 1 skip entry tests, 2 skip bucket loads, 4 skip desc writes, 8 no two-window descriptors
 };
 
@@ -889,65 +890,112 @@ struct __attribute__((packed, aligned(4))) u32x4_u {
   uint32_t x, y, z, w;
 };
 
-// confirm_pair -- cdiff for one candidate pair.  Loads the 2-bit read record (aligned,
-// neighbouring lanes mostly share it) and the target span at an arbitrary base offset
-// (dword-aligned 16-byte gathers + funnel shift), XOR + popcount = cdiff over the whole read
-// (cmd/muscato_confirm/main.go:151-159, 205-211; X==X through the mask plane), then decides
-// whether THIS window is the first window of the read that the reference would have emitted
-// the tuple through (exact window key + fit), which makes the union over windows a set
-// without a sort.  RW = record words (compile time) or 0 = runtime stride.
-// Returns the pair's result word (NX_REJECT, or nmiss | NX_DUP | window << 20 | slot << 24).
+// What one pair brings in from memory (static stride): descriptor, record, target span, masks.
 template <int RW, bool MASK>
+struct PairRegs {
+  uint4 ds;
+  uint32_t exact;  // rvalid of the read
+  uint32_t r[RW ? RW : 1], t[RW ? RW : 1], rm[(RW && MASK) ? RW : 1], tm[(RW && MASK) ? RW : 1];
+};
+
+// pair_issue: every load of the pair, nothing that needs their results -- so that a caller can
+// put other work between issue and finish
+template <int RW, bool MASK>
+DEV void pair_issue(PairRegs<RW, MASK>& P, const uint4 ds, const uint32_t* __restrict__ rd,
+                    const uint32_t* __restrict__ rdm, const uint32_t* __restrict__ db2,
+                    const uint32_t* __restrict__ dbm2, uint64_t r0, const uint32_t* __restrict__ rvalid) {
+  static_assert(RW != 0, "static stride only");
+  P.ds = ds;
+  const uint32_t ri = ds.x & 0xFFFFFFu;
+  const uint64_t gpos = (uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32);
+  const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)RW;
+  const uint64_t widx = gpos >> 4;
+  P.exact = rvalid[ri];
+  // read records stream through once: non-temporal, so that the database -- the only operand
+  // with reuse -- keeps the Infinity Cache
+#pragma unroll
+  for (int q = 0; q < RW / 4; q++) {
+    const u32x4_v a = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(rec) + q);
+    P.r[4 * q] = a.x; P.r[4 * q + 1] = a.y; P.r[4 * q + 2] = a.z; P.r[4 * q + 3] = a.w;
+    const u32x4_u b = *reinterpret_cast<const u32x4_u*>(db2 + widx + 4 * q);
+    P.t[4 * q] = b.x; P.t[4 * q + 1] = b.y; P.t[4 * q + 2] = b.z; P.t[4 * q + 3] = b.w;
+    if constexpr (MASK) {
+      const uint4 c = *reinterpret_cast<const uint4*>(rdm + (r0 + ri) * (uint64_t)RW + 4 * q);
+      P.rm[4 * q] = c.x; P.rm[4 * q + 1] = c.y; P.rm[4 * q + 2] = c.z; P.rm[4 * q + 3] = c.w;
+      const u32x4_u d = *reinterpret_cast<const u32x4_u*>(dbm2 + widx + 4 * q);
+      P.tm[4 * q] = d.x; P.tm[4 * q + 1] = d.y; P.tm[4 * q + 2] = d.z; P.tm[4 * q + 3] = d.w;
+    }
+  }
+}
+
+// The reference's confirm for window k (and for k + 1 when the descriptor stands for both)
+// accepts this pair -- it counts towards that window-key block's MaxMatches; the tuple is
+// reported here only if the first window that accepts it is one of this descriptor's.
+DEV uint32_t pair_code(const uint4 ds, uint32_t nx, uint32_t budget, uint32_t exact) {
+  const uint32_t ri = ds.x & 0xFFFFFFu, k = ds.z & 15u;
+  const bool within = nx <= budget;
+  const bool a0 = within && ((exact >> k) & 1u);
+  const bool a1 = within && (ds.z & DESC_TWO) && ((exact >> (k + 1)) & 1u);
+  if (!(a0 || a1)) return NX_REJECT;
+  const uint32_t kmin = (uint32_t)(__ffs(exact) - 1);
+  const bool first = (a0 && kmin == k) || (a1 && kmin == k + 1);
+  return (first ? nx : (nx | NX_DUP)) | (a0 ? NX_ACC0 : 0u) | (a1 ? NX_ACC1 : 0u) | (k << 20) | ((ri & (TILE - 1)) << 24);
+}
+
+// pair_finish: XOR + popcount = cdiff over the whole read (cmd/muscato_confirm/main.go:151-159,
+// 205-211; X==X through the mask plane) and, from the same mismatch mask, which windows of the
+// read match the target exactly here (the first-window rule that makes the union over windows a
+// set without a sort).  Returns the pair's result word.  budget_of(len) = the read's mismatch
+// budget.
+template <int RW, bool MASK, class BudgetOf>
+DEV uint32_t pair_finish(const PairRegs<RW, MASK>& P, const PathParams& pp, BudgetOf budget_of) {
+  const uint64_t gpos = (uint64_t)P.ds.y | ((uint64_t)(P.ds.x >> 24) << 32);
+  const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
+  uint32_t exact = P.exact;
+  if ((P.ds.z >> 4) & 1u) exact &= ~pp.q1zero_mask;
+  const uint32_t len = P.r[RW - 1] & 0xFFFFu;
+  const int len2 = 2 * (int)len;
+  uint32_t nx = 0;
+#pragma unroll
+  for (int j = 0; j < RW - 1; j++) {
+    const uint32_t tj = __funnelshift_r(P.t[j], P.t[j + 1], sh);
+    const uint32_t x = P.r[j] ^ tj;
+    uint32_t d = (x | (x >> 1)) & 0x55555555u;
+    if constexpr (MASK) d |= (P.rm[j] ^ __funnelshift_r(P.tm[j], P.tm[j + 1], sh)) & 0x55555555u;
+    const int rem = len2 - 32 * j;
+    d &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+    nx += __popc(d);
+    for (int kk = 0; kk < pp.W; kk++)
+      if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
+  }
+  return pair_code(P.ds, nx, budget_of(len), exact);
+}
+
+// confirm_pair -- cdiff for one candidate pair in one go.  Loads the 2-bit read record (aligned,
+// neighbouring lanes mostly share it) and the target span at an arbitrary base offset
+// (dword-aligned 16-byte gathers + funnel shift).  RW = record words (compile time) or 0 =
+// runtime stride.  Returns the pair's result word (NX_REJECT, or nmiss | flags | window << 20 |
+// slot << 24).
+template <int RW, bool MASK, class BudgetOf>
 DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
                           const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0,
-                          int rw_rt, const PathParams& pp, const uint16_t* __restrict__ nmiss_tab,
-                          const uint32_t* __restrict__ rvalid) {
-  const uint32_t ri = ds.x & 0xFFFFFFu;
-  const int rw = RW ? RW : rw_rt;
-  const uint64_t gpos = (uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32);
-  const uint32_t k = ds.z & 15u, z = (ds.z >> 4) & 1u;
-  const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)rw;
-  const uint64_t widx = gpos >> 4;
-  const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
-  uint32_t exact = rvalid[ri];
-  if (z) exact &= ~pp.q1zero_mask;
-
-  uint32_t nx = 0, len;
+                          int rw_rt, const PathParams& pp, BudgetOf budget_of, const uint32_t* __restrict__ rvalid) {
   if constexpr (RW != 0) {
-    // ---- static stride: whole record and span in registers, 16-byte loads.  Read records
-    // stream through once: non-temporal, so that the database -- the only operand with reuse --
-    // keeps the Infinity Cache
-    uint32_t r[RW], t[RW], rm[RW], tm[RW];
-#pragma unroll
-    for (int q = 0; q < RW / 4; q++) {
-      const u32x4_v a = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(rec) + q);
-      r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
-      const u32x4_u b = *reinterpret_cast<const u32x4_u*>(db2 + widx + 4 * q);
-      t[4 * q] = b.x; t[4 * q + 1] = b.y; t[4 * q + 2] = b.z; t[4 * q + 3] = b.w;
-      if (MASK) {
-        const uint4 c = *reinterpret_cast<const uint4*>(rdm + (r0 + ri) * (uint64_t)rw + 4 * q);
-        rm[4 * q] = c.x; rm[4 * q + 1] = c.y; rm[4 * q + 2] = c.z; rm[4 * q + 3] = c.w;
-        const u32x4_u d = *reinterpret_cast<const u32x4_u*>(dbm2 + widx + 4 * q);
-        tm[4 * q] = d.x; tm[4 * q + 1] = d.y; tm[4 * q + 2] = d.z; tm[4 * q + 3] = d.w;
-      }
-    }
-    len = r[RW - 1] & 0xFFFFu;
-    const int len2 = 2 * (int)len;
-#pragma unroll
-    for (int j = 0; j < RW - 1; j++) {
-      const uint32_t tj = __funnelshift_r(t[j], t[j + 1], sh);
-      const uint32_t x = r[j] ^ tj;
-      uint32_t d = (x | (x >> 1)) & 0x55555555u;
-      if (MASK) d |= (rm[j] ^ __funnelshift_r(tm[j], tm[j + 1], sh)) & 0x55555555u;
-      const int rem = len2 - 32 * j;
-      d &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-      nx += __popc(d);
-      for (int kk = 0; kk < pp.W; kk++)
-        if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
-    }
+    PairRegs<RW, MASK> P;
+    pair_issue<RW, MASK>(P, ds, rd, rdm, db2, dbm2, r0, rvalid);
+    return pair_finish<RW, MASK>(P, pp, budget_of);
   } else {
     // ---- runtime stride (reads longer than the compiled strides): streaming words
-    len = rec[rw - 1] & 0xFFFFu;
+    const uint32_t ri = ds.x & 0xFFFFFFu;
+    const int rw = rw_rt;
+    const uint64_t gpos = (uint64_t)ds.y | ((uint64_t)(ds.x >> 24) << 32);
+    const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)rw;
+    const uint64_t widx = gpos >> 4;
+    const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
+    uint32_t exact = rvalid[ri];
+    if ((ds.z >> 4) & 1u) exact &= ~pp.q1zero_mask;
+    uint32_t nx = 0;
+    const uint32_t len = rec[rw - 1] & 0xFFFFu;
     const int len2 = 2 * (int)len;
     const uint32_t* __restrict__ recm = MASK ? rdm + (r0 + ri) * (uint64_t)rw : nullptr;
     uint32_t tlo = db2[widx], tmlo = MASK ? dbm2[widx] : 0u;
@@ -967,20 +1015,17 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
       for (int kk = 0; kk < pp.W; kk++)
         if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
     }
+    return pair_code(ds, nx, budget_of(len), exact);
   }
-  // The reference's confirm for window k (and for k + 1 when the descriptor stands for both)
-  // accepts this pair -- it counts towards that window-key block's MaxMatches; the tuple is
-  // reported here only if the first window that accepts it is one of this descriptor's.
-  const bool within = nx <= nmiss_tab[len];
-  const bool a0 = within && ((exact >> k) & 1u);
-  const bool a1 = within && (ds.z & DESC_TWO) && ((exact >> (k + 1)) & 1u);
-  if (!(a0 || a1)) return NX_REJECT;
-  const uint32_t kmin = (uint32_t)(__ffs(exact) - 1);
-  const bool first = (a0 && kmin == k) || (a1 && kmin == k + 1);
-  return (first ? nx : (nx | NX_DUP)) | (a0 ? NX_ACC0 : 0u) | (a1 ? NX_ACC1 : 0u) | (k << 20) | ((ri & (TILE - 1)) << 24);
 }
 
 #define BLOCK_LDS_BITS 11  // sketch size
+#define CONF_NM 256        // read lengths whose mismatch budget k_confirm keeps in LDS
+#define CONF_TILES 32      // tiles per k_confirm workgroup (65536 tiles per batch / MAX_GRID = 16)
+
+// Barrier for phases that communicate through LDS only: unlike __syncthreads() it does not wait
+// for outstanding global loads and stores.
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #define CODE_CAP 1024      // result words beyond a lane's first kept in LDS; a larger tile spills the rest to p_nx
 
 // k_confirm -- muscato_confirm for one tile of k_screen per workgroup iteration, followed in
@@ -1004,8 +1049,11 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
 //   hold more than MaxMatches pairs (cells only over-estimate).  Otherwise counters[6] is raised
 //   and the host repeats the pass in mode 2.
 // block_mode 2: exact -- one global atomic per (read, window) into a 2^22-cell table.
+// (Eight waves per SIMD where the record fits 64 registers without spilling: measured 1.82 ms
+// per cfg3 pass against 1.95 ms at the compiler's own choice.  Prefetching the next tile's gathers across the select passes was tried and lost --
+// 2.1 ms: the registers it holds cost more waves than the overlap wins.)
 template <int RW, bool MASK>
-__global__ __launch_bounds__(TILE) void k_confirm(
+__global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void k_confirm(
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
     const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, uint32_t n, int rw_rt,
     PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
@@ -1019,21 +1067,34 @@ __global__ __launch_bounds__(TILE) void k_confirm(
   __shared__ uint32_t s_code[CODE_CAP];
   __shared__ uint32_t s_sketch[1 << BLOCK_LDS_BITS];
   __shared__ uint32_t s_wsum[TILE / 64];
+  __shared__ uint16_t s_nm[CONF_NM];                 // mismatch budget of the short read lengths
+  __shared__ uint32_t s_tb[CONF_TILES], s_tn[CONF_TILES];  // this workgroup's tiles: descriptor range
   const uint32_t ntiles = (n + TILE - 1) / TILE;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (block_mode == 1)
     for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += TILE) s_sketch[t] = 0;
+  for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)pp.max_len ? nmiss_tab[t] : (uint16_t)0;
+  // tile j of this workgroup = blockIdx.x + j * gridDim.x (the host keeps it to CONF_TILES)
+  const uint32_t my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+  for (uint32_t j = threadIdx.x; j < my_tiles && j < CONF_TILES; j += TILE) {
+    s_tb[j] = tbase[blockIdx.x + j * gridDim.x];
+    s_tn[j] = tcount[blockIdx.x + j * gridDim.x];
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) tcount2[ntiles] = 0;
   unsigned long long acc = 0;
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();  // the previous tile is done with the LDS state
+  auto budget_of = [&](uint32_t len) -> uint32_t { return len < CONF_NM ? s_nm[len] : nmiss_tab[len]; };
+  __syncthreads();
+
+  for (uint32_t j = 0; j < my_tiles; j++) {
+    const uint32_t tile = blockIdx.x + j * gridDim.x;
+    lds_barrier();  // the previous tile is done with the LDS state
     s_best[threadIdx.x] = 0xFFFFFFFFu;
     s_cnt[threadIdx.x] = 0;
     if (block_mode)
       for (uint32_t t = threadIdx.x; t < TILE * (uint32_t)pp.W; t += TILE) s_wcnt[t] = 0;
-    __syncthreads();
-    const uint32_t tn = tcount[tile];
-    const uint64_t tb = tbase[tile];
+    lds_barrier();
+    const uint32_t tn = s_tn[j];
+    const uint64_t tb = s_tb[j];
     // ---- pass 1.  The lane's first pair (five tiles in six have no second) stays in
     // registers through all three passes; later ones park their result word in LDS.
     auto tally = [&](uint32_t w) {
@@ -1054,7 +1115,7 @@ __global__ __launch_bounds__(TILE) void k_confirm(
       *gene = dsv.w;
       *zword = dsv.z;
       return confirm_pair<RW, MASK>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, r0, rw_rt, pp,
-                                    nmiss_tab, rvalid);
+                                    budget_of, rvalid);
     };
     uint32_t w0 = NX_REJECT, gene0 = 0, z0 = 0;
     if (threadIdx.x < tn) w0 = confirm_at(threadIdx.x, &gene0, &z0);
@@ -1065,7 +1126,7 @@ __global__ __launch_bounds__(TILE) void k_confirm(
       if (tj - TILE < CODE_CAP) s_code[tj - TILE] = w; else p_nx[tb + tj] = w;
       tally(w);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- pass 2
     auto count = [&](uint32_t w) {
       if (w == NX_REJECT || (w & NX_DUP)) return;
@@ -1086,7 +1147,7 @@ __global__ __launch_bounds__(TILE) void k_confirm(
         else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- scan of the per-read counts
     const uint32_t c = s_cnt[threadIdx.x];
     uint32_t inc = c;
@@ -1096,7 +1157,7 @@ __global__ __launch_bounds__(TILE) void k_confirm(
       if (lane >= d) inc += o;
     }
     if (lane == 63) s_wsum[wid] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t woff = 0, total = 0;
 #pragma unroll
     for (int q = 0; q < TILE / 64; q++) {
@@ -1106,7 +1167,7 @@ __global__ __launch_bounds__(TILE) void k_confirm(
     s_base[threadIdx.x] = woff + inc - c;
     s_cnt[threadIdx.x] = 0;  // now the arrival counter of the read
     if (threadIdx.x == 0) tcount2[tile] = total;
-    __syncthreads();
+    lds_barrier();
     // ---- pass 3
     if (total == 0) continue;
     auto emit = [&](uint32_t w, uint32_t tj, uint32_t gene, uint32_t zword) {
@@ -1134,7 +1195,7 @@ __global__ __launch_bounds__(TILE) void k_confirm(
   }
   block_add_u64(acc, &counters[1]);
   if (block_mode == 1) {
-    __syncthreads();
+    lds_barrier();
     uint32_t hot = 0;
     for (uint32_t t = threadIdx.x; t < (1u << BLOCK_LDS_BITS); t += TILE) hot |= s_sketch[t] >= block_thr;
     if (__any(hot) && (threadIdx.x & 63) == 0) atomicOr(&counters[6], 1ull);
@@ -1515,6 +1576,7 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
   } else {
     // persistent over tiles; the MaxMatches screening threshold assumes at most MAX_GRID workgroups
     const dim3 grid(std::min(nblk(n, TILE), MAX_GRID));
+    static_assert((1u << 24) / TILE / MAX_GRID <= CONF_TILES, "a k_confirm workgroup keeps its tile list in LDS");
     const size_t lds = c->cur_block_mode ? (size_t)TILE * pp.W * 4 : 0;
     if (mask)
       hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
@@ -1933,6 +1995,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   pp.mmtol = P->mmtol > 0xFFFF ? 0xFFFF : P->mmtol;
   pp.apply_mmtol = P->apply_mmtol;
   pp.wide = c->wide;
+  pp.max_len = (int32_t)c->max_len;
   if (const char* dv = getenv("MUSC_DEBUG_SCREEN")) pp.dbg = atoi(dv);
   for (int k = 0; k < pp.W; k++) {
     pp.win[k] = P->windows[k];
