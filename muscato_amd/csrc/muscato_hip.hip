@@ -561,6 +561,7 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 #define WB_NONE 0xFFFFFFFFu
 
 #define TILE 256  // reads per tile = threads per workgroup of k_screen
+#define CONF_NM 256  // read lengths whose mismatch budget the kernels keep in LDS
 
 // k_screen -- muscato_screen + the join, fused: one workgroup iteration per tile of 256 reads.
 // For each window of a read that takes part (cmd/muscato_window_reads/main.go:106-118 ==
@@ -614,6 +615,10 @@ DEV bool screen_entry_ok(const uint4 ent, int q1, int ww, uint32_t rfl, uint32_t
   return ok;
 }
 
+// Barrier for phases that communicate through LDS only: unlike __syncthreads() it does not wait
+// for outstanding global loads and stores (descriptor and tuple stores drain in the background).
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values derived from x across loop iterations
   asm volatile("" : "+v"(x));
   return x;
@@ -659,6 +664,9 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
   __shared__ uint32_t s_pref[SCR_PROBES + 1];  // exclusive prefix of s_oc
   __shared__ uint16_t s_own[SCR_OWN];          // flat item -> probe
   __shared__ uint32_t s_tilecnt;               // survivors of the tile so far
+  __shared__ uint16_t s_nm[CONF_NM];           // mismatch budget of the short read lengths
+  for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)pp.max_len ? nmiss_tab[t] : (uint16_t)0;
+  lds_barrier();
   const int rw = RW ? RW : rw_rt;
   constexpr bool has_m = MASK;  // the mask planes exist (some read or target holds an X)
   const uint32_t ntiles = (n + TILE - 1) / TILE;
@@ -677,9 +685,9 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       const uint32_t o = __shfl_up(inc, d);
       if (lane >= d) inc += o;
     }
-    __syncthreads();  // earlier readers of s_wsum are done
+    lds_barrier();  // earlier readers of s_wsum are done
     if (lane == 63) s_wsum[wid] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t woff = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < TILE / 64; w++) {
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       if constexpr (has_m) return recm_store; else return rec;  // never read without a mask plane
     }();
     const int len = (int)rec.len();
-    const uint32_t budget = nmiss_tab[len];
+    const uint32_t budget = len < CONF_NM ? s_nm[len] : nmiss_tab[len];
     uint32_t valid = 0;
     if (tida == 0) s_tilecnt = 0;
     const uint64_t base = region0 + used;
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
         }
         s_bb[2 * tida + j] = b;
       }
-      __syncthreads();
+      lds_barrier();
       // ---- phase B: buckets by quads; a wave fetches the 128 probes of its own 64 reads
 #pragma unroll 1
       for (int h = 0; h < ((pp.dbg & 256) ? 0 : 8 / SCR_ROUNDS); h++) {
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
           append(ok, v[rr], probe, k, q1, z, two);
         }
       }
-      __syncthreads();
+      lds_barrier();
       // ---- phase C: the chunk's overflow entries as one flat list, in (read, window, entry) order
       const uint32_t tidc = opaque(threadIdx.x);
       if (pp.dbg & 256) continue;
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
         if (tidc == TILE - 1) s_pref[SCR_PROBES] = total;
         for (uint32_t e = 0; e < oc0 && pre + e < SCR_OWN; e++) s_own[pre + e] = (uint16_t)(2 * tidc);
         for (uint32_t e = 0; e < oc1 && pre + oc0 + e < SCR_OWN; e++) s_own[pre + oc0 + e] = (uint16_t)(2 * tidc + 1);
-        __syncthreads();
+        lds_barrier();
         for (uint32_t t0 = 0; t0 < total; t0 += TILE) {
           const uint32_t t = t0 + tidc;
           bool ok = t < total;
@@ -852,7 +860,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
           append(ok, ent, seg, k, q1, z, false);
         }
       }
-      __syncthreads();  // the LDS tables are reused by the next chunk
+      lds_barrier();  // the LDS tables are reused by the next chunk
     }
     nvalid += __popc(valid);
     if (active) rvalid[i] = valid;
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       tbase[tile] = (uint32_t)base;
       tcount[tile] = fits ? total : 0u;
     }
-    __syncthreads();  // before the next tile resets s_tilecnt
+    lds_barrier();  // before the next tile resets s_tilecnt
   }
   block_add_u64(nvalid, &counters[0]);
   block_add_u64(ncand, &counters[3]);
@@ -1020,12 +1028,9 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
 }
 
 #define BLOCK_LDS_BITS 11  // sketch size
-#define CONF_NM 256        // read lengths whose mismatch budget k_confirm keeps in LDS
 #define CONF_TILES 32      // tiles per k_confirm workgroup (65536 tiles per batch / MAX_GRID = 16)
 
-// Barrier for phases that communicate through LDS only: unlike __syncthreads() it does not wait
-// for outstanding global loads and stores.
-DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define CODE_CAP 1024      // result words beyond a lane's first kept in LDS; a larger tile spills the rest to p_nx
 
 // k_confirm -- muscato_confirm for one tile of k_screen per workgroup iteration, followed in
