@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmuscato_hip.so")
 SOURCES = [os.path.join(CSRC, "muscato_hip.hip")]
-HEADERS = [os.path.join(os.path.dirname(HERE), "include", "muscato_hip.h"), os.path.join(CSRC, "muscato_prep.hpp")]
+HEADERS = [os.path.join(os.path.dirname(HERE), "include", "muscato_hip.h")] + \
+    [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
 
 
 def hipcc() -> str:
