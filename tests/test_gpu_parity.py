@@ -285,6 +285,28 @@ def test_packed_tuples_roundtrip(eng):
         eng.hits_to_packed(words.ctypes.data, n, False, [32, 32, 32, 8])
 
 
+def test_sixteen_windows(eng):
+    """The maximum number of windows (eight chunks of two in k_screen, a 16 KB window-counter
+    block in k_confirm), overlapping and at odd offsets, with a tight MaxMatches check."""
+    from muscato_amd import sorted_hits
+    reads, targets = synthetic_medium(77, 1500, 20000, tlen=600, L=100)
+    wins = [0, 3, 7, 11, 16, 22, 29, 31, 37, 41, 48, 53, 59, 66, 73, 80]
+    c = orc.Config(Windows=wins, WindowWidth=12, PMatch=0.95, MinDinuc=2, MaxReadLength=100, MaxMatches=1000000, MMTol=1)
+    rbuf, roff = literal.concat(reads)
+    gbuf, goff = literal.concat(targets)
+    exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff,
+                                     literal.make_params(c, bloom_size=64_000_000, num_hash=6, nthreads=8))
+    got = gpu_hits(eng, c, reads, targets, False)
+    assert len(got) > 5000
+    assert_same(got, exp)
+    assert eng.stats()["n_overflow_blocks"] == 0
+    best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
+    assert_same(best, as_arr(orc.best_filter([tuple(int(x) for x in r) for r in exp], 1)))
+    with pytest.raises(RuntimeError, match="at most 16 windows"):
+        c17 = orc.Config(Windows=wins + [85], WindowWidth=12, PMatch=0.95, MaxReadLength=100)
+        gpu_hits(eng, c17, reads[:10], targets[:10], False)
+
+
 def test_stats_and_repeat_calls_are_stable(eng):
     from muscato_amd import sorted_hits
     ocfg, reads, targets = make_case(4)
