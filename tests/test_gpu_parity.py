@@ -307,6 +307,39 @@ def test_sixteen_windows(eng):
         gpu_hits(eng, c17, reads[:10], targets[:10], False)
 
 
+def test_low_complexity_stress(eng):
+    """Poly-A-like targets and reads: every window key occurs at almost every target position,
+    so one tile of 100 reads carries millions of descriptors (overflow lists of ~30 000 entries
+    per bucket, result words spilling past the LDS buffer, region growth + batch repeat).  Tuples
+    against the literal oracle; MaxMatches small enough to be reached must be reported."""
+    from muscato_amd import sorted_hits
+    rng = np.random.default_rng(5)
+
+    def lowc(n, rate):
+        a = np.full(n, ord("A"), dtype=np.uint8)
+        m = rng.random(n) < rate
+        a[m] = np.frombuffer(b"CGT", dtype=np.uint8)[rng.integers(0, 3, size=int(m.sum()))]
+        return bytes(a)
+    targets = [lowc(1000, 0.01) for _ in range(32)]
+    reads = sorted({lowc(int(rng.integers(30, 61)), 0.02) for _ in range(100)})
+    c = orc.Config(Windows=[0, 12], WindowWidth=8, PMatch=0.9, MinDinuc=0, MaxReadLength=60,
+                   MaxMatches=1_000_000_000, MMTol=0)
+    rbuf, roff = literal.concat(reads)
+    gbuf, goff = literal.concat(targets)
+    exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff,
+                                     literal.make_params(c, bloom_size=64_000_000, num_hash=6, nthreads=8))
+    got = gpu_hits(eng, c, reads, targets, False)
+    st = eng.stats()
+    assert st["n_descriptors"] > 1_000_000 and len(got) > 500_000
+    assert_same(got, exp)
+    assert st["n_overflow_blocks"] == 0
+    best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
+    assert_same(best, as_arr(orc.best_filter([tuple(int(x) for x in r) for r in exp], 0)))
+    c.MaxMatches = 10000
+    gpu_hits(eng, c, reads, targets, False)
+    assert eng.stats()["n_overflow_blocks"] >= 1 and len(eng.overflow_probes()) >= 1
+
+
 def test_stats_and_repeat_calls_are_stable(eng):
     from muscato_amd import sorted_hits
     ocfg, reads, targets = make_case(4)
