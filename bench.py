@@ -121,6 +121,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unsorted", action="store_true", help="leave the unique reads in random order")
     ap.add_argument("--no-block-check", action="store_true", help="skip the MaxMatches per-block overflow check")
+    ap.add_argument("--xrate", type=float, default=0.0,
+                    help="fraction of bases replaced by X in targets and reads (the correctness/timing run with the mask planes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,6 +171,12 @@ def main() -> int:
 
     t0 = time.time()
     targets = synth.gen_targets(wl, device, seed)
+    if args.xrate > 0:
+        gx = torch.Generator(device=device)
+        gx.manual_seed(seed + 99)
+        for s0 in range(0, wl.n_targets, 100_000):
+            blk = targets[s0:s0 + 100_000]
+            blk[torch.rand(blk.shape, device=device, generator=gx) < args.xrate] = ord("X")
     toff = synth.offsets_for(wl.n_targets, wl.target_len, device)
     torch.cuda.synchronize()
     log("generated %d targets x %d bp in %.1fs" % (wl.n_targets, wl.target_len, time.time() - t0))
@@ -186,6 +194,10 @@ def main() -> int:
     t0 = time.time()
     U = wl.n_unique_reads
     reads = synth.gen_unique_reads(wl, targets, device, seed + 7919 * (rank + 1))
+    if args.xrate > 0:
+        for s0 in range(0, reads.shape[0], 1_000_000):
+            blk = reads[s0:s0 + 1_000_000]
+            blk[torch.rand(blk.shape, device=device, generator=gx) < args.xrate] = ord("X")
     if not args.unsorted:
         reads = synth.sort_reads(reads)  # the hot path's input is reads_sorted.txt.sz
     roff = synth.offsets_for(U, wl.read_len, device)
@@ -340,7 +352,7 @@ def main() -> int:
                 "targets": wl.n_targets, "target_len": wl.target_len, "read_len": wl.read_len,
                 "Windows": list(wl.windows), "WindowWidth": wl.window_width, "PMatch": wl.pmatch,
                 "MMTol": wl.mmtol, "MinDinuc": wl.min_dinuc, "MaxMatches": wl.max_matches,
-                "MatchMode": wl.match_mode, "read_order": "random" if args.unsorted else "bytewise sorted (reads_sorted)",
+                "MatchMode": wl.match_mode, "x_rate": args.xrate, "read_order": "random" if args.unsorted else "bytewise sorted (reads_sorted)",
                 "parallelism": "reads sharded x%d, database replicated" % world, "gather": gather_mode[0],
                 "timed_region": "unique reads + database + index resident in HBM -> hits in HBM"
                                 + (" gathered on rank 0 (RCCL, gather of pass i overlapped with pass i+1)" if world > 1 else ""),

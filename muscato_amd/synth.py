@@ -127,10 +127,10 @@ def gen_unique_reads(wl: Workload, targets_ascii: torch.Tensor, device, seed: in
 def sort_reads(reads: torch.Tensor) -> torch.Tensor:
     """Bytewise (LC_ALL=C) sort of fixed-length ASCII reads -- the order of the reference's
     reads_sorted.txt.sz, which is what its hot path consumes (cmd/muscato/main.go:180-189).
-    LSD radix over 25-base digits; A<C<G<T in ASCII, so 2-bit codes keep the order."""
+    LSD radix over 25-base digits; A<C<G<T<X in ASCII, so the codes 0..4 keep the order."""
     n, L = reads.shape
     dev = reads.device
-    code = torch.zeros(256, dtype=torch.int64, device=dev)
+    code = torch.full((256,), 4, dtype=torch.int64, device=dev)  # anything else is the reference's X
     for i, c in enumerate(_ASCII):
         code[c] = i
     perm = torch.arange(n, device=dev)
@@ -139,8 +139,8 @@ def sort_reads(reads: torch.Tensor) -> torch.Tensor:
         lo, hi = d * 25, min(L, d * 25 + 25)
         key = torch.zeros(n, dtype=torch.int64, device=dev)
         for j in range(lo, hi):
-            key = key * 4 + code[reads[:, j].long()]
-        key = key * (4 ** (25 - (hi - lo)))
+            key = key * 5 + code[reads[:, j].long()]
+        key = key * (5 ** (25 - (hi - lo)))
         order = torch.sort(key[perm], stable=True).indices
         perm = perm[order]
         del key, order
