@@ -7,6 +7,7 @@
 // ------------------------------------------------------------------------------------
 
 #define DEV __device__ __forceinline__
+#define READ_HAS_X 0x10000u  // length word of a read record, bit 16: the read holds an X
 
 DEV uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
@@ -116,6 +117,25 @@ __global__ void k_pack_db_packed(const uint32_t* __restrict__ in2, const uint16_
   if (mv) atomicOr(has_x, 1u);
 }
 
+// dbx: one bit per block of 64 database bases (4 words of the mask plane), set when the block
+// holds an X.  2 MB per Gbp: stays in L2, so k_confirm gathers the mask plane only for the few
+// spans that need it.
+__global__ void k_db_xblocks(const uint32_t* __restrict__ dbm2, uint64_t nwords, uint32_t* __restrict__ dbx) {
+  const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk * 4 >= nwords) return;
+  uint32_t any = 0;
+  for (int q = 0; q < 4; q++)
+    if (blk * 4 + q < nwords) any |= dbm2[blk * 4 + q];
+  if (any) atomicOr(&dbx[blk >> 5], 1u << (blk & 31));
+}
+
+DEV bool db_span_has_x(const uint32_t* __restrict__ dbx, uint64_t gpos, uint32_t nbases) {
+  const uint64_t b0 = gpos >> 6, b1 = (gpos + nbases - 1) >> 6;  // at most 64 blocks apart for the spans used
+  const uint64_t w = (uint64_t)dbx[b0 >> 5] | ((uint64_t)dbx[(b0 >> 5) + 1] << 32);
+  const uint32_t nb = (uint32_t)(b1 - b0) + 1;
+  return ((w >> (b0 & 31)) & (nb >= 32 ? 0xFFFFFFFFull : ((1ull << nb) - 1ull))) != 0;
+}
+
 __global__ void k_max_len(const uint64_t* __restrict__ off, uint64_t n, unsigned long long* out) {
   __shared__ unsigned long long s_m[16];
   unsigned long long l = 0;
@@ -149,7 +169,20 @@ __global__ void k_pack_reads(const unsigned char* __restrict__ s, const uint32_t
   const uint64_t o = off[r];
   const uint32_t len = (uint32_t)(off[r + 1] - o);
   if (j == rw - 1) {
-    rd[t] = len & 0xFFFFu;
+    // length word: bits 0-15 the length, bit 16 (READ_HAS_X) set when the read holds an X --
+    // the kernels fetch a read's mask words only then
+    uint32_t anyx = 0;
+    for (uint32_t q = 0; q < len; q++) {
+      if (PACKED) {
+        const uint64_t g = o + q;
+        anyx |= inm ? ((inm[g >> 5] >> (g & 31)) & 1u) : 0u;
+      } else {
+        uint32_t isx;
+        (void)ascii_code(s[o + q], &isx);
+        anyx |= isx;
+      }
+    }
+    rd[t] = (len & 0xFFFFu) | (anyx ? READ_HAS_X : 0u);
     rdm[t] = 0;
     return;
   }

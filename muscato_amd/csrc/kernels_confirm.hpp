@@ -15,7 +15,8 @@ struct PairRegs {
 template <int RW, bool MASK>
 DEV void pair_issue(PairRegs<RW, MASK>& P, const uint4 ds, const uint32_t* __restrict__ rd,
                     const uint32_t* __restrict__ rdm, const uint32_t* __restrict__ db2,
-                    const uint32_t* __restrict__ dbm2, uint64_t r0, const uint32_t* __restrict__ rvalid) {
+                    const uint32_t* __restrict__ dbm2, const uint32_t* __restrict__ dbx, uint64_t r0,
+                    const uint32_t* __restrict__ rvalid) {
   static_assert(RW != 0, "static stride only");
   P.ds = ds;
   const uint32_t ri = ds.x & 0xFFFFFFu;
@@ -23,6 +24,14 @@ DEV void pair_issue(PairRegs<RW, MASK>& P, const uint4 ds, const uint32_t* __res
   const uint32_t* __restrict__ rec = rd + (r0 + ri) * (uint64_t)RW;
   const uint64_t widx = gpos >> 4;
   P.exact = rvalid[ri];
+  // Mask words are fetched only where an X can be: the read says so in its descriptor, the
+  // database in a bitmap of 64-base blocks that stays in L2 (X is rare and clustered; most
+  // pairs then cost what they cost without mask planes).
+  bool rx = false, tx = false;
+  if constexpr (MASK) {
+    rx = (ds.z & DESC_RX) != 0;
+    tx = db_span_has_x(dbx, gpos, RW * 16);
+  }
   // read records stream through once: non-temporal, so that the database -- the only operand
   // with reuse -- keeps the Infinity Cache
 #pragma unroll
@@ -32,9 +41,11 @@ DEV void pair_issue(PairRegs<RW, MASK>& P, const uint4 ds, const uint32_t* __res
     const u32x4_u b = *reinterpret_cast<const u32x4_u*>(db2 + widx + 4 * q);
     P.t[4 * q] = b.x; P.t[4 * q + 1] = b.y; P.t[4 * q + 2] = b.z; P.t[4 * q + 3] = b.w;
     if constexpr (MASK) {
-      const uint4 c = *reinterpret_cast<const uint4*>(rdm + (r0 + ri) * (uint64_t)RW + 4 * q);
+      uint4 c = make_uint4(0, 0, 0, 0);
+      if (rx) c = *reinterpret_cast<const uint4*>(rdm + (r0 + ri) * (uint64_t)RW + 4 * q);
       P.rm[4 * q] = c.x; P.rm[4 * q + 1] = c.y; P.rm[4 * q + 2] = c.z; P.rm[4 * q + 3] = c.w;
-      const u32x4_u d = *reinterpret_cast<const u32x4_u*>(dbm2 + widx + 4 * q);
+      u32x4_u d = {0, 0, 0, 0};
+      if (tx) d = *reinterpret_cast<const u32x4_u*>(dbm2 + widx + 4 * q);
       P.tm[4 * q] = d.x; P.tm[4 * q + 1] = d.y; P.tm[4 * q + 2] = d.z; P.tm[4 * q + 3] = d.w;
     }
   }
@@ -65,7 +76,7 @@ DEV uint32_t pair_finish(const PairRegs<RW, MASK>& P, const PathParams& pp, Budg
   const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
   uint32_t exact = P.exact;
   if ((P.ds.z >> 4) & 1u) exact &= ~pp.q1zero_mask;
-  const uint32_t len = P.r[RW - 1] & 0xFFFFu;
+  const uint32_t len = P.r[RW - 1] & 0xFFFFu;  // (bit 16 of the word is READ_HAS_X)
   const int len2 = 2 * (int)len;
   uint32_t nx = 0;
 #pragma unroll
@@ -90,11 +101,12 @@ DEV uint32_t pair_finish(const PairRegs<RW, MASK>& P, const PathParams& pp, Budg
 // slot << 24).
 template <int RW, bool MASK, class BudgetOf>
 DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
-                          const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0,
-                          int rw_rt, const PathParams& pp, BudgetOf budget_of, const uint32_t* __restrict__ rvalid) {
+                          const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2,
+                          const uint32_t* __restrict__ dbx, uint64_t r0, int rw_rt, const PathParams& pp,
+                          BudgetOf budget_of, const uint32_t* __restrict__ rvalid) {
   if constexpr (RW != 0) {
     PairRegs<RW, MASK> P;
-    pair_issue<RW, MASK>(P, ds, rd, rdm, db2, dbm2, r0, rvalid);
+    pair_issue<RW, MASK>(P, ds, rd, rdm, db2, dbm2, dbx, r0, rvalid);
     return pair_finish<RW, MASK>(P, pp, budget_of);
   } else {
     // ---- runtime stride (reads longer than the compiled strides): streaming words
@@ -164,7 +176,8 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
 template <int RW, bool MASK>
 __global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void k_confirm(
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
-    const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, uint64_t r0, uint32_t n, int rw_rt,
+    const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, const uint32_t* __restrict__ dbx,
+    uint64_t r0, uint32_t n, int rw_rt,
     PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
     const uint32_t* __restrict__ rvalid, uint32_t* __restrict__ p_nx,
     const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ tcount,
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void
       const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + tb + tj);
       *gene = dsv.w;
       *zword = dsv.z;
-      return confirm_pair<RW, MASK>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, r0, rw_rt, pp,
+      return confirm_pair<RW, MASK>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, dbx, r0, rw_rt, pp,
                                     budget_of, rvalid);
     };
     uint32_t w0 = NX_REJECT, gene0 = 0, z0 = 0;

@@ -37,6 +37,11 @@ struct Rec {
     }
   }
   DEV uint32_t len() const { return w[RW - 1] & 0xFFFFu; }
+  DEV bool has_x() const { return (w[RW - 1] & READ_HAS_X) != 0; }
+  DEV void zero() {
+#pragma unroll
+    for (int q = 0; q < RW; q++) w[q] = 0;
+  }
   // 64 bits from bit offset bo.  bo is wave-uniform in every caller, so the word index is
   // resolved by a scalar branch and each case names its registers statically (a chain of
   // per-word selects costs 3*RW VALU per call instead).
@@ -71,6 +76,7 @@ struct Rec<0> {
   int rw;
   DEV void load(const uint32_t* __restrict__ q, int rw_rt) { p = q; rw = rw_rt; }
   DEV uint32_t len() const { return p[rw - 1] & 0xFFFFu; }
+  DEV bool has_x() const { return (p[rw - 1] & READ_HAS_X) != 0; }
   DEV uint64_t ext(uint32_t bo) const { return ext64(p, bo); }
 };
 
@@ -132,6 +138,7 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 #define NX_ACC1 0x20000u  // the descriptor's second window (k + 1) accepts the pair
 #define NX_ACC0 0x40000u  // the descriptor's window k accepts the pair
 #define DESC_TWO (1u << 22)  // descriptor z: windows k and k + 1 both found this placement
+#define DESC_RX (1u << 23)   // descriptor z: the read holds an X (its mask words are needed)
 #define BLOCK_TABLE_BITS 22
 #define WB_NONE 0xFFFFFFFFu
 
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
   __shared__ uint32_t s_pref[SCR_PROBES + 1];  // exclusive prefix of s_oc
   __shared__ uint16_t s_own[SCR_OWN];          // flat item -> probe
   __shared__ uint32_t s_tilecnt;               // survivors of the tile so far
+  __shared__ uint8_t s_rx[TILE];               // the read holds an X (mask planes only)
   __shared__ uint16_t s_nm[CONF_NM];           // mismatch budget of the short read lengths
   for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)pp.max_len ? nmiss_tab[t] : (uint16_t)0;
   lds_barrier();
@@ -281,7 +289,12 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
     Rec<RW> rec;
     rec.load(rd + r * (uint64_t)rw, rw);
     Rec<has_m ? RW : -1> recm_store;
-    if constexpr (has_m) recm_store.load(rdm + r * (uint64_t)rw, rw);
+    if constexpr (has_m) {
+      // the mask words only of reads that hold an X (flag in the length word)
+      if (RW == 0 || rec.has_x()) recm_store.load(rdm + r * (uint64_t)rw, rw);
+      else if constexpr (RW != 0) recm_store.zero();
+    }
+    if constexpr (has_m) s_rx[tida] = rec.has_x() ? 1 : 0;
     const auto& recm = [&]() -> const Rec<RW>& {
       if constexpr (has_m) return recm_store; else return rec;  // never read without a mask plane
     }();
@@ -308,7 +321,8 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
         // global offset of the placement (40 bits in wide mode: the high byte rides in x)
         const uint64_t gp = (((uint64_t)(pp.wide ? ent.x >> 24 : 0u) << 32) | ent.y) - (uint64_t)q1;
         desc[base + slot] = make_uint4((tile * TILE + (probe >> 1)) | ((uint32_t)(gp >> 32) << 24), (uint32_t)gp,
-                                       (uint32_t)k | (z << 4) | (pos_ok << 5) | ((left - (uint32_t)q1) << 6) | (two ? DESC_TWO : 0u),
+                                       (uint32_t)k | (z << 4) | (pos_ok << 5) | ((left - (uint32_t)q1) << 6) | (two ? DESC_TWO : 0u) |
+                                           ((has_m && s_rx[probe >> 1]) ? DESC_RX : 0u),
                                        pp.wide ? (ent.x & 0xFFFFFFu) : ent.x);
       }
     };

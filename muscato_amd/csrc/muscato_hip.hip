@@ -65,6 +65,7 @@ struct musc_ctx {
   // database
   uint32_t* db2 = nullptr;
   uint32_t* dbm2 = nullptr;  // null when the database holds no X
+  uint32_t* dbx = nullptr;   // with dbm2: one bit per 64-base block that holds an X
   uint64_t* seq_off = nullptr;
   uint32_t nseq = 0;
   uint64_t nbases = 0;
@@ -233,8 +234,9 @@ void free_db(musc_ctx* c) {
   free_index(c);
   if (c->db2) (void)hipFree(c->db2);
   if (c->dbm2) (void)hipFree(c->dbm2);
+  if (c->dbx) (void)hipFree(c->dbx);
   if (c->seq_off) (void)hipFree(c->seq_off);
-  c->db2 = c->dbm2 = nullptr;
+  c->db2 = c->dbm2 = c->dbx = nullptr;
   c->seq_off = nullptr;
   c->nseq = 0;
   c->nbases = 0;
@@ -315,12 +317,12 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
     static_assert((1u << 24) / TILE / MAX_GRID <= CONF_TILES, "a k_confirm workgroup keeps its tile list in LDS");
     const size_t lds = c->cur_block_mode ? (size_t)TILE * pp.W * 4 : 0;
     if (mask)
-      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
+      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, c->dbx, r0, n,
                          c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p, c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
                          c->bs[c->cur].wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
                          c->tcount2.p, c->counters);
     else
-      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, r0, n,
+      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, c->dbx, r0, n,
                          c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p, c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
                          c->bs[c->cur].wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
                          c->tcount2.p, c->counters);
@@ -418,6 +420,20 @@ void musc_destroy(musc_ctx* c) {
 
 // ---------------------------------------------------------------- database
 
+// the X-block bitmap of the mask plane (all zero for a plane that exists only because reads hold X)
+static int db_xblocks(musc_ctx* c) {
+  const uint64_t nblk64 = (c->db_words + 64 + 3) / 4;
+  const uint64_t nw = nblk64 / 32 + 4;
+  if (c->dbx) (void)hipFree(c->dbx);
+  c->dbx = nullptr;
+  HIPCHK(c, hipMalloc((void**)&c->dbx, nw * 4));
+  HIPCHK(c, hipMemsetAsync(c->dbx, 0, nw * 4, c->stream));
+  hipLaunchKernelGGL(k_db_xblocks, dim3(nblk(nblk64, 256)), dim3(256), 0, c->stream, c->dbm2, c->db_words, c->dbx);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 static int db_finish(musc_ctx* c, uint32_t* d_hasx) {
   uint32_t hasx = 0;
   HIPCHK(c, hipMemcpyAsync(&hasx, d_hasx, 4, hipMemcpyDeviceToHost, c->stream));
@@ -426,8 +442,9 @@ static int db_finish(musc_ctx* c, uint32_t* d_hasx) {
   if (!hasx) {
     (void)hipFree(c->dbm2);
     c->dbm2 = nullptr;
+    return 0;
   }
-  return 0;
+  return db_xblocks(c);
 }
 
 static int db_alloc(musc_ctx* c, const uint64_t* offsets, uint32_t nseq, int on_device, uint32_t** d_hasx) {
@@ -788,6 +805,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipMalloc((void**)&c->dbm2, (c->db_words + 64) * 4));
     // (the index stays valid: bucket_of treats a null and an all-zero mask plane alike)
     HIPCHK(c, hipMemsetAsync(c->dbm2, 0, (c->db_words + 64) * 4, c->stream));
+    if ((rc = db_xblocks(c))) return rc;
   }
 
   // Per batch: k_screen claims descriptor space as it goes; if a batch needs more than the

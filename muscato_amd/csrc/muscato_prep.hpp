@@ -106,7 +106,13 @@ __global__ void k_prep_pack(const unsigned char* __restrict__ s, const uint64_t*
   const uint64_t o = off[r];
   const uint32_t len = (uint32_t)(off[r + 1] - o);
   if (j == rw - 1) {
-    rd[t] = len & 0xFFFFu;
+    uint32_t anyx = 0;
+    for (uint32_t q = 0; q < len; q++) {
+      uint32_t isx;
+      (void)ascii_code(s[o + q], &isx);
+      anyx |= isx;
+    }
+    rd[t] = (len & 0xFFFFu) | (anyx ? READ_HAS_X : 0u);
     rdm[t] = 0;
     return;
   }
