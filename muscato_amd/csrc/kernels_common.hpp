@@ -67,7 +67,9 @@ DEV void block_add_u64(unsigned long long v, unsigned long long* dst) {
   __syncthreads();
 }
 
+#ifndef MAX_GRID
 #define MAX_GRID 4096u  // grid-stride kernels: enough blocks to fill 256 CUs several times
+#endif
 
 // ------------------------------------------------------------------------------------
 // packing kernels (ASCII / 2-bit stream -> device layout)
