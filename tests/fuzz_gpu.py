@@ -1,0 +1,39 @@
+"""Long-running fuzz of the GPU path (not collected by pytest): `python tests/fuzz_gpu.py LO HI`
+runs make_case(seed) for seed in [LO, HI) through one Engine -- all accepted tuples, best+MMTol
+twice (the second pass is sync-free), and the same reads through the GPU read prep -- against
+the Python oracle.  Round 1: seeds 120..60000, no mismatch (150 s on one MI355X)."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from cases import make_case
+from oracle import muscato_oracle as orc
+from muscato_amd import Engine, Config, sorted_hits
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+e = Engine(0)
+bad = 0
+t0 = time.time()
+for seed in range(lo, hi):
+    ocfg, reads, targets = make_case(seed)
+    full = sorted(orc.match_direct(reads, targets, ocfg))
+    best = sorted(orc.best_filter(full, ocfg.MMTol))
+    e.load_targets(targets); e.load_reads(reads)
+    cfg = Config(Windows=list(ocfg.Windows), WindowWidth=ocfg.WindowWidth, PMatch=ocfg.PMatch, MinDinuc=ocfg.MinDinuc, MaxReadLength=ocfg.MaxReadLength, MaxMatches=ocfg.MaxMatches, MMTol=ocfg.MMTol, MatchMode=ocfg.MatchMode)
+    for mode, exp in ((False, full), (True, best), (True, best)):
+        got = [tuple(int(x) for x in r) for r in sorted_hits(e.match(cfg, apply_mmtol=mode))]
+        if got != exp:
+            bad += 1
+            print("MISMATCH seed", seed, "apply_mmtol", mode, len(got), len(exp), flush=True)
+    # the same reads through the GPU prep, shuffled with duplicates
+    raw = list(reads) + list(reads[::3])
+    rng = np.random.default_rng(seed); rng.shuffle(raw)
+    order, ustart = e.sort_unique_reads(raw)
+    if [raw[i] for i in order[ustart[:-1]]] != list(reads):
+        bad += 1; print("PREP MISMATCH seed", seed, flush=True)
+    got = [tuple(int(x) for x in r) for r in sorted_hits(e.match(cfg, apply_mmtol=False))]
+    if got != full:
+        bad += 1; print("MISMATCH after prep, seed", seed, flush=True)
+    if seed % 200 == 0: print("seed", seed, "elapsed %.0fs" % (time.time() - t0), flush=True)
+print("fuzz", lo, hi, "bad", bad, "in %.0fs" % (time.time() - t0))
