@@ -1,0 +1,82 @@
+"""Medium-scale fuzz of the GPU path against the literal C++ oracle (not collected by pytest):
+`python tests/fuzz_gpu_medium.py LO HI` draws one random configuration per seed -- 1-5 windows,
+WindowWidth 6-20 (direct and hashed index), PMatch 0.9-1, MinDinuc 0-6, MMTol 0-3, X rate 0 / 0.1 % /
+1 %, read length 40-150 -- over a few thousand reads and a few hundred targets, and compares all
+accepted tuples and the best+MMTol selection.  Round 1: seeds 0..30000, no mismatch (10 min on
+one MI355X)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from oracle import literal
+from oracle import muscato_oracle as orc
+from muscato_amd import Config, Engine, sorted_hits
+
+
+def case(seed):
+    rng = np.random.default_rng(seed)
+    L = int(rng.choice([40, 60, 100, 120, 150]))
+    ww = int(rng.integers(6, 21))
+    nwin = int(rng.integers(1, 6))
+    wins = sorted(int(x) for x in rng.choice(np.arange(0, max(1, L - ww - 5)), size=nwin, replace=False))
+    if rng.random() < 0.5:
+        wins[0] = 0
+    cfg = orc.Config(Windows=wins, WindowWidth=ww, PMatch=float(rng.choice([1.0, 0.97, 0.95, 0.92, 0.9])),
+                     MinDinuc=int(rng.integers(0, 7)), MaxReadLength=L, MaxMatches=1000000,
+                     MMTol=int(rng.integers(0, 4)), MatchMode=str(rng.choice(["best", "first"])))
+    nt, tlen, nr = int(rng.integers(50, 400)), int(rng.integers(L + 5, 800)), int(rng.integers(500, 6000))
+    xrate = float(rng.choice([0.0, 0.001, 0.01]))
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    T = bases[rng.integers(0, 4, size=(nt, tlen))]
+    ncopy = nt // 4
+    T[nt - ncopy:] = T[rng.integers(0, nt - ncopy, size=ncopy)]
+    sub = rng.random((ncopy, tlen)) < 0.03
+    T[nt - ncopy:][sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    if xrate:
+        T[rng.random(T.shape) < xrate] = ord("X")
+    g = rng.integers(0, nt, size=nr)
+    p = rng.integers(0, tlen - L + 1, size=nr)
+    p[rng.random(nr) < 0.05] = 0
+    p[rng.random(nr) < 0.05] = tlen - L
+    R = T[g[:, None], p[:, None] + np.arange(L)[None, :]].copy()
+    sub = rng.random(R.shape) < float(rng.choice([0.0, 0.01, 0.03]))
+    R[sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    if xrate:
+        R[rng.random(R.shape) < xrate] = ord("X")
+    lens = rng.integers(max(ww, L // 2), L + 1, size=nr)
+    reads = sorted({bytes(r[:n]) for r, n in zip(R, lens)})
+    return cfg, reads, [bytes(t) for t in T]
+
+
+def main():
+    lo, hi = int(sys.argv[1]), int(sys.argv[2])
+    e = Engine(0)
+    bad, t0 = 0, time.time()
+    for seed in range(lo, hi):
+        c, reads, targets = case(seed)
+        rbuf, roff = literal.concat(reads)
+        gbuf, goff = literal.concat(targets)
+        exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff, literal.make_params(c, bloom_size=16_000_000, num_hash=6, nthreads=8))
+        e.load_targets(targets)
+        e.load_reads(reads)
+        k = Config(Windows=list(c.Windows), WindowWidth=c.WindowWidth, PMatch=c.PMatch, MinDinuc=c.MinDinuc,
+                   MaxReadLength=c.MaxReadLength, MaxMatches=c.MaxMatches, MMTol=c.MMTol, MatchMode=c.MatchMode)
+        got = sorted_hits(e.match(k, apply_mmtol=False))
+        ok = got.shape == exp.shape and bool((got == exp).all())
+        best = sorted_hits(e.match(k, apply_mmtol=True))
+        eb = np.array(sorted(orc.best_filter([tuple(int(x) for x in r) for r in exp], c.MMTol)), dtype=np.uint32).reshape(-1, 4)
+        ok = ok and best.shape == eb.shape and bool((best == eb).all()) and e.stats()["n_overflow_blocks"] == 0
+        if not ok:
+            bad += 1
+            print("MISMATCH seed", seed, c, len(reads), len(targets), len(got), len(exp), flush=True)
+        if seed % 50 == 0:
+            print("seed", seed, "hits", len(exp), "elapsed %.0fs" % (time.time() - t0), flush=True)
+    print("fuzz_medium", lo, hi, "bad", bad, "in %.0fs" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
