@@ -212,8 +212,10 @@ DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values der
 #ifndef SCR_WAVES
 #define SCR_WAVES 4  // waves per SIMD the register allocator has to leave room for
 #endif
-template <int RW, bool MASK>
-__global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __restrict__ rd,
+// ONE: at most two windows, i.e. a single chunk -- the compiler then keeps nothing alive across
+// chunks (59 instead of 80 VGPRs without mask planes) and eight waves fit a SIMD.
+template <int RW, bool MASK, bool ONE>
+__global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen(const uint32_t* __restrict__ rd,
                                                  const uint32_t* __restrict__ rdm, uint64_t r0,
                                                  uint32_t n, int rw_rt, PathParams pp,
                                                  const uint16_t* __restrict__ nmiss_tab,
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(TILE, SCR_WAVES) void k_screen(const uint32_t* __re
       }
     };
 
-    for (int k0 = 0; k0 < pp.W; k0 += 2) {
+    for (int k0 = 0; k0 < (ONE ? 1 : pp.W); k0 += 2) {
       // ---- phase A: which of this read's next two windows take part, and their buckets
       const int q1a = pp.win[k0], q1b = pp.win[k0 + 1 < pp.W ? k0 + 1 : k0];
 #pragma unroll

@@ -303,14 +303,16 @@ template <int RW>
 void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp) {
   const dim3 block(TILE);
   if (stage == 0) {
-    if (c->rdm)
-      hipLaunchKernelGGL((k_screen<RW, true>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd,
-                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,
-                         c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, c->counters + 8);
-    else
-      hipLaunchKernelGGL((k_screen<RW, false>), dim3(std::min(nblk(n, TILE), MAX_GRID)), block, 0, c->stream, c->rd,
-                         c->rdm, r0, n, c->rw, pp, c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,
-                         c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, c->counters + 8);
+    const dim3 sgrid(std::min(nblk(n, TILE), MAX_GRID));
+#define MUSC_LAUNCH_SCREEN(M, O)                                                                                  \
+    hipLaunchKernelGGL((k_screen<RW, M, O>), sgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp,          \
+                       c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,        \
+                       c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, \
+                       c->counters + 8)
+    const bool one = pp.W <= 2;
+    if (c->rdm) { if (one) MUSC_LAUNCH_SCREEN(true, true); else MUSC_LAUNCH_SCREEN(true, false); }
+    else { if (one) MUSC_LAUNCH_SCREEN(false, true); else MUSC_LAUNCH_SCREEN(false, false); }
+#undef MUSC_LAUNCH_SCREEN
   } else {
     // persistent over tiles; the MaxMatches screening threshold assumes at most MAX_GRID workgroups
     const dim3 grid(std::min(nblk(n, TILE), MAX_GRID));
