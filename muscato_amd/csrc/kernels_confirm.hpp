@@ -70,7 +70,9 @@ DEV uint32_t pair_code(const uint4 ds, uint32_t nx, uint32_t budget, uint32_t ex
 // read match the target exactly here (the first-window rule that makes the union over windows a
 // set without a sort).  Returns the pair's result word.  budget_of(len) = the read's mismatch
 // budget.
-template <int RW, bool MASK, class BudgetOf>
+// W2: at most two windows -- the per-window loop is then two unrolled steps (measured: 4 % of
+// the kernel; with a run-time bound the scalar unit recomputes the window masks per word).
+template <int RW, bool MASK, bool W2, class BudgetOf>
 DEV uint32_t pair_finish(const PairRegs<RW, MASK>& P, const PathParams& pp, BudgetOf budget_of) {
   const uint64_t gpos = (uint64_t)P.ds.y | ((uint64_t)(P.ds.x >> 24) << 32);
   const uint32_t sh = ((uint32_t)gpos & 15u) * 2u;
@@ -88,8 +90,14 @@ DEV uint32_t pair_finish(const PairRegs<RW, MASK>& P, const PathParams& pp, Budg
     const int rem = len2 - 32 * j;
     d &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
     nx += __popc(d);
-    for (int kk = 0; kk < pp.W; kk++)
-      if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
+    if constexpr (W2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+        if (kk < pp.W && (d & window_word_mask(pp.win[kk], pp.ww, j))) exact &= ~(1u << kk);
+    } else {
+      for (int kk = 0; kk < pp.W; kk++)
+        if (d & window_word_mask(pp.win[kk], pp.ww, j)) exact &= ~(1u << kk);
+    }
   }
   return pair_code(P.ds, nx, budget_of(len), exact);
 }
@@ -99,7 +107,7 @@ DEV uint32_t pair_finish(const PairRegs<RW, MASK>& P, const PathParams& pp, Budg
 // (dword-aligned 16-byte gathers + funnel shift).  RW = record words (compile time) or 0 =
 // runtime stride.  Returns the pair's result word (NX_REJECT, or nmiss | flags | window << 20 |
 // slot << 24).
-template <int RW, bool MASK, class BudgetOf>
+template <int RW, bool MASK, bool W2, class BudgetOf>
 DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
                           const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2,
                           const uint32_t* __restrict__ dbx, uint64_t r0, int rw_rt, const PathParams& pp,
@@ -107,7 +115,7 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
   if constexpr (RW != 0) {
     PairRegs<RW, MASK> P;
     pair_issue<RW, MASK>(P, ds, rd, rdm, db2, dbm2, dbx, r0, rvalid);
-    return pair_finish<RW, MASK>(P, pp, budget_of);
+    return pair_finish<RW, MASK, W2>(P, pp, budget_of);
   } else {
     // ---- runtime stride (reads longer than the compiled strides): streaming words
     const uint32_t ri = ds.x & 0xFFFFFFu;
@@ -173,7 +181,7 @@ DEV uint32_t confirm_pair(const uint4 ds, const uint32_t* __restrict__ rd, const
 // (Eight waves per SIMD where the record fits 64 registers without spilling: measured 1.82 ms
 // per cfg3 pass against 1.95 ms at the compiler's own choice.  Prefetching the next tile's gathers across the select passes was tried and lost --
 // 2.1 ms: the registers it holds cost more waves than the overlap wins.)
-template <int RW, bool MASK>
+template <int RW, bool MASK, bool W2>
 __global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void k_confirm(
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
     const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, const uint32_t* __restrict__ dbx,
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void
       const u32x4_v dsv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(cdesc) + tb + tj);
       *gene = dsv.w;
       *zword = dsv.z;
-      return confirm_pair<RW, MASK>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, dbx, r0, rw_rt, pp,
+      return confirm_pair<RW, MASK, W2>(make_uint4(dsv.x, dsv.y, dsv.z, dsv.w), rd, rdm, db2, dbm2, dbx, r0, rw_rt, pp,
                                     budget_of, rvalid);
     };
     uint32_t w0 = NX_REJECT, gene0 = 0, z0 = 0;

@@ -318,16 +318,16 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
     const dim3 grid(std::min(nblk(n, TILE), MAX_GRID));
     static_assert((1u << 24) / TILE / MAX_GRID <= CONF_TILES, "a k_confirm workgroup keeps its tile list in LDS");
     const size_t lds = c->cur_block_mode ? (size_t)TILE * pp.W * 4 : 0;
-    if (mask)
-      hipLaunchKernelGGL((k_confirm<RW, true>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, c->dbx, r0, n,
-                         c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p, c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
-                         c->bs[c->cur].wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
-                         c->tcount2.p, c->counters);
-    else
-      hipLaunchKernelGGL((k_confirm<RW, false>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2, c->dbx, r0, n,
-                         c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p, c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
-                         c->bs[c->cur].wb.p, c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p,
-                         c->tcount2.p, c->counters);
+#define MUSC_LAUNCH_CONFIRM(M, W2)                                                                                 \
+    hipLaunchKernelGGL((k_confirm<RW, M, W2>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2,      \
+                       c->dbx, r0, n, c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p,     \
+                       c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, c->bs[c->cur].wb.p,                \
+                       c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p, c->tcount2.p, \
+                       c->counters)
+    const bool w2 = pp.W <= 2;
+    if (mask) { if (w2) MUSC_LAUNCH_CONFIRM(true, true); else MUSC_LAUNCH_CONFIRM(true, false); }
+    else { if (w2) MUSC_LAUNCH_CONFIRM(false, true); else MUSC_LAUNCH_CONFIRM(false, false); }
+#undef MUSC_LAUNCH_CONFIRM
   }
 }
 
