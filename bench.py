@@ -343,7 +343,8 @@ def main() -> int:
         bytes_launch = acc["bytes"] / max(acc["launches"], 1)
         achieved = (bytes_launch / 1e9) / (ms_launch / 1e3) if ms_launch > 0 else 0.0
         res = {
-            "metric": "reads/sec (100 bp, multi-map) through screen+confirm",
+            "metric": "reads/sec (100 bp, multi-map) at 1/2/4/8 MI355X; confirm-kernel HBM GB/s vs peak",  # BASELINE.json's wording: value = reads/sec, the confirm kernel is under "roofline"
+            
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
