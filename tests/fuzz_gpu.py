@@ -1,7 +1,7 @@
 """Long-running fuzz of the GPU path (not collected by pytest): `python tests/fuzz_gpu.py LO HI`
 runs make_case(seed) for seed in [LO, HI) through one Engine -- all accepted tuples, best+MMTol
 twice (the second pass is sync-free), and the same reads through the GPU read prep -- against
-the Python oracle.  Round 1: seeds 120..60000, no mismatch (150 s on one MI355X)."""
+the Python oracle.  Round 1: seeds 0..100000 with the final kernels, no mismatch (270 s on one MI355X)."""
 import os
 import sys
 import time
