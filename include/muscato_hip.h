@@ -93,8 +93,9 @@ typedef struct {
    * reference's truncation, cmd/muscato_confirm/main.go:233-242, 424-448, never triggered and
    * the tuples are exact); > 0 = upper bound; ~0 = check skipped */
   uint64_t n_overflow_blocks;
-  uint64_t confirm_bytes;   /* algorithmic bytes of the confirm launches: 63 B per candidate
-                             * pair at 100 bp + 16 B per tuple written      */
+  uint64_t confirm_bytes;   /* algorithmic bytes of the confirm launches: 63 B per DESCRIPTOR
+                             * loaded at 100 bp (descriptor 12 + record 25 + target span 26,
+                             * SURVEY.md 8d) + 16 B per tuple written                       */
   uint32_t confirm_launches;
   uint32_t n_batches;
   float ms_screen;          /* HIP-event time of each kernel family, summed over batches:  */

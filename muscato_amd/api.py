@@ -90,7 +90,10 @@ class Config:
             c.ResultsFileName = "results.txt"
         return c
 
-    def to_params(self, apply_mmtol: bool, skip_block_check: bool = False) -> _lib.MuscParams:
+    def to_params(self, apply_mmtol: bool, skip_block_check: bool = False, n_shards: int = 1) -> _lib.MuscParams:
+        """n_shards > 1: this context sees one of n_shards contiguous slices of the reads, so a
+        (window,key) block is split across contexts and the MaxMatches check must use
+        MaxMatches / n_shards (include/muscato_hip.h, musc_params.n_shards)."""
         c = self.with_defaults()
         if len(c.Windows) > _lib.MUSC_MAX_WINDOWS:
             raise MuscatoError("at most %d windows are supported" % _lib.MUSC_MAX_WINDOWS)
@@ -108,6 +111,7 @@ class Config:
         p.apply_mmtol = 1 if apply_mmtol else 0
         p.max_mismatch_p1 = c.MaxMismatch + 1 if c.MaxMismatch >= 0 else 0
         p.skip_block_check = 1 if skip_block_check else 0
+        p.n_shards = max(1, int(n_shards))
         return p
 
 
@@ -244,10 +248,20 @@ class Engine:
                     "musc_reads_load_packed")
         self.n_reads = len(off) - 1
 
+    def load_reads_packed_ptr(self, bases_ptr: int, mask_ptr: int, off_ptr: int, nreads: int) -> None:
+        """musc_reads_load_packed on caller-owned host buffers (e.g. pinned memory): 2-bit bases,
+        optional 1-bit X mask (0 = none), uint64 offsets[nreads + 1] in bases."""
+        self._check(self._lib.musc_reads_load_packed(self._h, bases_ptr, mask_ptr or None, off_ptr, nreads),
+                    "musc_reads_load_packed")
+        self.n_reads = nreads
+
     # ---- hot path
-    def match_device(self, cfg: Config, apply_mmtol: bool = True, skip_block_check: bool = False) -> int:
-        """Run screen+confirm(+select); hits stay on the device.  Returns the hit count."""
-        p = cfg.to_params(apply_mmtol, skip_block_check)
+    def match_device(self, cfg: Config, apply_mmtol: bool = True, skip_block_check: bool = False,
+                     n_shards: int = 1) -> int:
+        """Run screen+confirm(+select); hits stay on the device.  Returns the hit count.
+        n_shards = number of read shards the (window,key) blocks are split over (world size of a
+        one-process-per-GPU run): the MaxMatches proof then holds for the union of the shards."""
+        p = cfg.to_params(apply_mmtol, skip_block_check, n_shards)
         n = ctypes.c_uint64()
         self._check(self._lib.musc_match_device(self._h, ctypes.byref(p), ctypes.byref(n)), "musc_match_device")
         return int(n.value)
@@ -265,9 +279,9 @@ class Engine:
         b = (ctypes.c_int32 * 4)(*bits)
         self._check(self._lib.musc_hits_unpack(self._h, src_ptr, n, 1 if on_device else 0, b, dst_ptr), "musc_hits_unpack")
 
-    def match(self, cfg: Config, apply_mmtol: bool = True) -> np.ndarray:
+    def match(self, cfg: Config, apply_mmtol: bool = True, n_shards: int = 1) -> np.ndarray:
         """-> uint32 array [n, 4] of (read_idx, gene_idx, pos, nmiss), order unspecified."""
-        n = self.match_device(cfg, apply_mmtol)
+        n = self.match_device(cfg, apply_mmtol, n_shards=n_shards)
         out = np.zeros((n, 4), dtype=np.uint32)
         if n:
             self.hits_to(out.ctypes.data, n, False)

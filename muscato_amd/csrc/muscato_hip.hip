@@ -42,7 +42,7 @@
 
 namespace {
 
-std::string g_init_error;
+thread_local std::string g_init_error;  // musc_init may run on one host thread per GPU
 
 template <class T>
 struct DevBuf {
@@ -53,6 +53,27 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+};
+
+// temporary device allocations of one call, released on every exit path
+struct TmpBufs {
+  void* p[16] = {};
+  int n = 0;
+  template <class T>
+  hipError_t alloc(T** out, size_t bytes) {
+    void* q = nullptr;
+    *out = nullptr;
+    if (n >= 16) return hipErrorOutOfMemory;  // (more allocations than this helper was sized for)
+    const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    if (e == hipSuccess) p[n++] = q;
+    *out = (T*)q;
+    return e;
+  }
+  void release() {
+    for (int i = 0; i < n; i++) (void)hipFree(p[i]);
+    n = 0;
+  }
+  ~TmpBufs() { release(); }
 };
 
 }  // namespace
@@ -127,6 +148,14 @@ struct musc_ctx {
   bool sized_exact_blocks = false;
   uint32_t sized_bsz = 0;        // reads per batch it ended up with
   musc_stats stats;
+  // timing events are created once and reused by every pass (creating and destroying a pair per
+  // kernel family per batch cost more than the kernels of a small pass)
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  // the mismatch-budget table on the device is valid for these inputs
+  double nm_pmatch = -1.0;
+  int32_t nm_mmp1 = -1;
+  uint32_t nm_maxlen = 0xFFFFFFFFu;
 };
 
 namespace {
@@ -256,18 +285,33 @@ struct EvPair {
   hipEvent_t a, b;
 };
 
+// an event of the context's pool (created on first use, destroyed with the context)
+hipEvent_t pool_event(musc_ctx* c) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->ev_pool.push_back(e);
+  }
+  return c->ev_pool[c->ev_used++];
+}
+
+// HIP-event timing of the kernel families of one pass; the events belong to the context's pool
 struct Timer {
   musc_ctx* c;
   std::vector<EvPair> ev[5];
-  explicit Timer(musc_ctx* ctx) : c(ctx) {}
+  explicit Timer(musc_ctx* ctx) : c(ctx) { c->ev_used = 0; }
   int begin(int fam, hipStream_t s = nullptr) {
     EvPair p;
-    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return 1;
+    p.a = pool_event(c);
+    p.b = pool_event(c);
+    if (!p.a || !p.b) return 1;
     (void)hipEventRecord(p.a, s ? s : c->stream);
     ev[fam].push_back(p);
     return 0;
   }
-  void end(int fam, hipStream_t s = nullptr) { (void)hipEventRecord(ev[fam].back().b, s ? s : c->stream); }
+  void end(int fam, hipStream_t s = nullptr) {
+    if (!ev[fam].empty()) (void)hipEventRecord(ev[fam].back().b, s ? s : c->stream);
+  }
   float total(int fam) {
     float t = 0;
     for (auto& p : ev[fam]) {
@@ -275,13 +319,6 @@ struct Timer {
       if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) t += ms;
     }
     return t;
-  }
-  ~Timer() {
-    for (auto& v : ev)
-      for (auto& p : v) {
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
-      }
   }
 };
 
@@ -378,6 +415,7 @@ int musc_init(int device_ordinal, musc_ctx** out) {
       (e = hipEventCreateWithFlags(&c->ev_free[1], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
       (e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
+      (e = hipMalloc((void**)&c->d_flag, 4)) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(uint64_t))) != hipSuccess) {
     fail(nullptr, 3, "musc_init: %s", hipGetErrorString(e));
     musc_destroy(c);
@@ -415,6 +453,7 @@ void musc_destroy(musc_ctx* c) {
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   for (hipEvent_t ev : {c->ev_ready[0], c->ev_ready[1], c->ev_free[0], c->ev_free[1], c->ev_join})
     if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -436,11 +475,10 @@ static int db_xblocks(musc_ctx* c) {
   return 0;
 }
 
-static int db_finish(musc_ctx* c, uint32_t* d_hasx) {
+static int db_finish(musc_ctx* c) {
   uint32_t hasx = 0;
-  HIPCHK(c, hipMemcpyAsync(&hasx, d_hasx, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&hasx, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_hasx);
   if (!hasx) {
     (void)hipFree(c->dbm2);
     c->dbm2 = nullptr;
@@ -449,7 +487,7 @@ static int db_finish(musc_ctx* c, uint32_t* d_hasx) {
   return db_xblocks(c);
 }
 
-static int db_alloc(musc_ctx* c, const uint64_t* offsets, uint32_t nseq, int on_device, uint32_t** d_hasx) {
+static int db_alloc(musc_ctx* c, const uint64_t* offsets, uint32_t nseq, int on_device) {
   HIPCHK(c, hipSetDevice(c->device));
   free_db(c);
   if (nseq == 0) return fail(c, 2, "database has no sequences");
@@ -474,61 +512,55 @@ static int db_alloc(musc_ctx* c, const uint64_t* offsets, uint32_t nseq, int on_
   HIPCHK(c, hipMalloc((void**)&c->seq_off, ((uint64_t)nseq + 1) * 8));
   HIPCHK(c, hipMemcpyAsync(c->seq_off, offsets, ((uint64_t)nseq + 1) * 8,
                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMalloc((void**)d_hasx, 4));
-  HIPCHK(c, hipMemsetAsync(*d_hasx, 0, 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, c->stream));  // raised by the packing kernel when it meets an X
   return 0;
 }
 
 int musc_db_load_ascii(musc_ctx* c, const char* seqs, const uint64_t* offsets, uint32_t nseq, int on_device) {
   if (!c) return 1;
   if (!seqs || !offsets) return fail(c, 2, "musc_db_load_ascii: NULL input");
-  uint32_t* d_hasx = nullptr;
-  int rc = db_alloc(c, offsets, nseq, on_device, &d_hasx);
+  int rc = db_alloc(c, offsets, nseq, on_device);
   if (rc) return rc;
   const unsigned char* src = (const unsigned char*)seqs;
+  TmpBufs B;
   unsigned char* tmp = nullptr;
   if (!on_device && c->nbases) {
-    HIPCHK(c, hipMalloc((void**)&tmp, c->nbases));
+    HIPCHK(c, B.alloc(&tmp, c->nbases));
     HIPCHK(c, hipMemcpyAsync(tmp, seqs, c->nbases, hipMemcpyHostToDevice, c->stream));
     src = tmp;
   }
   if (c->db_words) {
     hipLaunchKernelGGL(k_pack_db_ascii, dim3(nblk(c->db_words, 256)), dim3(256), 0, c->stream, src, c->nbases,
-                       c->db2, c->dbm2, c->db_words, d_hasx);
+                       c->db2, c->dbm2, c->db_words, c->d_flag);
     HIPCHK(c, hipGetLastError());
   }
-  rc = db_finish(c, d_hasx);
-  if (tmp) (void)hipFree(tmp);
-  return rc;
+  return db_finish(c);
 }
 
 int musc_db_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t* nmask, const uint64_t* seq_offsets,
                         uint32_t nseq) {
   if (!c) return 1;
   if (!bases2bit || !seq_offsets) return fail(c, 2, "musc_db_load_packed: NULL input");
-  uint32_t* d_hasx = nullptr;
-  int rc = db_alloc(c, seq_offsets, nseq, 0, &d_hasx);
+  int rc = db_alloc(c, seq_offsets, nseq, 0);
   if (rc) return rc;
+  TmpBufs B;
   uint32_t* t2 = nullptr;
   uint16_t* tm = nullptr;
   const uint64_t w = c->db_words;
   if (w) {
-    HIPCHK(c, hipMalloc((void**)&t2, w * 4));
+    HIPCHK(c, B.alloc(&t2, w * 4));
     HIPCHK(c, hipMemsetAsync(t2, 0, w * 4, c->stream));
     HIPCHK(c, hipMemcpyAsync(t2, bases2bit, (c->nbases + 3) / 4, hipMemcpyHostToDevice, c->stream));
     if (nmask) {
-      HIPCHK(c, hipMalloc((void**)&tm, w * 2));
+      HIPCHK(c, B.alloc(&tm, w * 2));
       HIPCHK(c, hipMemsetAsync(tm, 0, w * 2, c->stream));
       HIPCHK(c, hipMemcpyAsync(tm, nmask, (c->nbases + 7) / 8, hipMemcpyHostToDevice, c->stream));
     }
     hipLaunchKernelGGL(k_pack_db_packed, dim3(nblk(w, 256)), dim3(256), 0, c->stream, t2, tm, c->db2, c->dbm2, w,
-                       d_hasx);
+                       c->d_flag);
     HIPCHK(c, hipGetLastError());
   }
-  rc = db_finish(c, d_hasx);
-  if (t2) (void)hipFree(t2);
-  if (tm) (void)hipFree(tm);
-  return rc;
+  return db_finish(c);
 }
 
 int musc_db_build_index(musc_ctx* c, int32_t ww) {
@@ -559,9 +591,9 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
     if (v >= 8 && v <= 31) { bits = v; direct = 0; }
   }
   const uint64_t nb = 1ull << bits;
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
+  c->ev_used = 0;
+  hipEvent_t e0 = pool_event(c), e1 = pool_event(c), e2 = pool_event(c), e3 = pool_event(c);
+  if (!e0 || !e1 || !e2 || !e3) return fail(c, 10, "hipEventCreate failed");
   if (c->idx_T_cap < nb + 1) {
     if (c->idx_T) (void)hipFree(c->idx_T);
     c->idx_T = nullptr;
@@ -569,9 +601,10 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
     HIPCHK(c, hipMalloc((void**)&c->idx_T, (nb + 1) * sizeof(Bucket)));
     c->idx_T_cap = nb + 1;
   }
+  TmpBufs B;
   uint64_t *tmp = nullptr, *stmp = nullptr;
-  HIPCHK(c, hipMalloc((void**)&tmp, (nb + 1 + 16) * 8));
-  HIPCHK(c, hipMalloc((void**)&stmp, scan_tmp_elems(nb + 1) * 8));
+  HIPCHK(c, B.alloc(&tmp, (nb + 1 + 16) * 8));
+  HIPCHK(c, B.alloc(&stmp, scan_tmp_elems(nb + 1) * 8));
   // timed: the device work (allocation above and below is host time, seconds for a 64 GiB table
   // the first time, and not repeated)
   HIPCHK(c, hipEventRecord(e0, c->stream));
@@ -591,13 +624,9 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 8, hipMemcpyDeviceToHost, c->stream));
   hipLaunchKernelGGL(k_index_ovf_set, dim3(nblk(nb, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
   HIPCHK(c, hipGetLastError());
-  hipEvent_t e2, e3;
-  HIPCHK(c, hipEventCreate(&e2));
-  HIPCHK(c, hipEventCreate(&e3));
   HIPCHK(c, hipEventRecord(e2, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(tmp);
-  (void)hipFree(stmp);
+  B.release();  // 8 bytes per bucket: returned before the overflow array is allocated
   c->idx_novf = novf;
   if (c->idx_E_cap < novf + 16) {
     if (c->idx_E) (void)hipFree(c->idx_E);
@@ -617,7 +646,6 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   float ms = 0, ms2 = 0;
   (void)hipEventElapsedTime(&ms, e0, e2);
   (void)hipEventElapsedTime(&ms2, e3, e1);
-  for (hipEvent_t ev : {e0, e1, e2, e3}) (void)hipEventDestroy(ev);
   c->stats.ms_index_build = ms + ms2;
   c->idx_ww = ww;
   c->idx_bits = bits;
@@ -637,10 +665,11 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
     c->rw = 4;
     return 0;
   }
+  TmpBufs B;
   uint64_t* d_off = nullptr;
   const uint64_t* offp = offsets;
   if (!on_device) {
-    HIPCHK(c, hipMalloc((void**)&d_off, (nreads + 1) * 8));
+    HIPCHK(c, B.alloc(&d_off, (nreads + 1) * 8));
     HIPCHK(c, hipMemcpyAsync(d_off, offsets, (nreads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     offp = d_off;
   }
@@ -661,31 +690,30 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
   if (rw < 4) rw = 4;
   c->rw = rw;
   const uint64_t words = nreads * (uint64_t)rw;
+  if (words >= (1ull << 32)) return fail(c, 2, "too many read words for one dispatch (reads x record words >= 2^32)");
   HIPCHK(c, hipMalloc((void**)&c->rd, words * 4 + 256));
   HIPCHK(c, hipMalloc((void**)&c->rdm, words * 4 + 256));
   HIPCHK(c, hipMemsetAsync(c->rd + words, 0, 256, c->stream));
   HIPCHK(c, hipMemsetAsync(c->rdm + words, 0, 256, c->stream));
-  uint32_t* d_hasx = nullptr;
-  HIPCHK(c, hipMalloc((void**)&d_hasx, 4));
+  uint32_t* d_hasx = c->d_flag;
   HIPCHK(c, hipMemsetAsync(d_hasx, 0, 4, c->stream));
-  void *t1 = nullptr, *t2 = nullptr;
-  if (words >= (1ull << 32)) return fail(c, 2, "too many read words for one dispatch (reads x record words >= 2^32)");
+  unsigned char *t1 = nullptr, *t2 = nullptr;
   if (!packed) {
     const unsigned char* src = ascii;
     if (!on_device && total) {
-      HIPCHK(c, hipMalloc(&t1, total));
+      HIPCHK(c, B.alloc(&t1, total));
       HIPCHK(c, hipMemcpyAsync(t1, ascii, total, hipMemcpyHostToDevice, c->stream));
-      src = (const unsigned char*)t1;
+      src = t1;
     }
     hipLaunchKernelGGL(k_pack_reads<false>, dim3(nblk(words, 256)), dim3(256), 0, c->stream, src,
                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, offp, nreads, rw, c->rd, c->rdm, d_hasx);
   } else {
     const uint64_t b2 = ((total + 3) / 4 + 7) & ~3ull, bm = ((total + 7) / 8 + 7) & ~3ull;
-    HIPCHK(c, hipMalloc(&t1, b2 + 16));
+    HIPCHK(c, B.alloc(&t1, b2 + 16));
     HIPCHK(c, hipMemsetAsync(t1, 0, b2 + 16, c->stream));
     HIPCHK(c, hipMemcpyAsync(t1, bases2bit, (total + 3) / 4, hipMemcpyHostToDevice, c->stream));
     if (nmask) {
-      HIPCHK(c, hipMalloc(&t2, bm + 16));
+      HIPCHK(c, B.alloc(&t2, bm + 16));
       HIPCHK(c, hipMemsetAsync(t2, 0, bm + 16, c->stream));
       HIPCHK(c, hipMemcpyAsync(t2, nmask, (total + 7) / 8, hipMemcpyHostToDevice, c->stream));
     }
@@ -697,10 +725,6 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
   uint32_t hasx = 0;
   HIPCHK(c, hipMemcpyAsync(&hasx, d_hasx, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_hasx);
-  if (t1) (void)hipFree(t1);
-  if (t2) (void)hipFree(t2);
-  if (d_off) (void)hipFree(d_off);
   if (!hasx) {
     (void)hipFree(c->rdm);
     c->rdm = nullptr;
@@ -759,7 +783,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
 
   // nmiss budget per read length: int((1-PMatch)*float64(len)), IEEE double, truncation
   // (cmd/muscato_confirm/main.go:198) -- evaluated on the host exactly as Go does.
-  {
+  if (c->nm_pmatch != P->pmatch || c->nm_mmp1 != P->max_mismatch_p1 || c->nm_maxlen != c->max_len || !c->nmiss_tab.p) {
     std::vector<uint16_t> tab((size_t)c->max_len + 2);
     for (uint32_t L = 0; L < tab.size(); L++) {
       volatile double a = 1.0 - P->pmatch;
@@ -774,6 +798,9 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->nmiss_tab.p, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // tab goes out of scope
+    c->nm_pmatch = P->pmatch;
+    c->nm_mmp1 = P->max_mismatch_p1;
+    c->nm_maxlen = c->max_len;
   }
 
   HIPCHK(c, hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
@@ -791,9 +818,8 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
   }
   Timer tm(c);
-  hipEvent_t ev0, ev1;
-  HIPCHK(c, hipEventCreate(&ev0));
-  HIPCHK(c, hipEventCreate(&ev1));
+  hipEvent_t ev0 = pool_event(c), ev1 = pool_event(c);
+  if (!ev0 || !ev1) return fail(c, 10, "hipEventCreate failed");
   HIPCHK(c, hipEventRecord(ev0, c->stream));
 
   const bool mask = c->rdm || c->dbm2;
@@ -945,8 +971,6 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if (c->h_pinned[3]) {
       // a guard fired: the pass did not fit after all -- forget the sizing and run it the careful way
       c->sized_epoch = 0;
-      (void)hipEventDestroy(ev0);
-      (void)hipEventDestroy(ev1);
       return musc_match_device(c, P, nhits);
     }
     n_windows = c->h_pinned[8];  // the batch-local block accumulated over the whole pass
@@ -954,8 +978,6 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     n_pairs = c->h_pinned[8 + 4];
     n_two = c->h_pinned[8 + 5];
   } else if (c->h_pinned[3]) {
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     return fail(c, 12, "internal: a capacity guard fired although every batch was sized (flags %llu)",
                 (unsigned long long)c->h_pinned[3]);
   }
@@ -972,8 +994,6 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     // screening inconclusive (a hot sketch cell, or more launches than the threshold assumed):
     // repeat the pass with exact per-block counters
     c->force_exact_blocks = true;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     rc = musc_match_device(c, P, nhits);
     c->force_exact_blocks = false;
     return rc;
@@ -984,12 +1004,13 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   c->stats.ms_confirm = tm.total(3);
   c->stats.ms_select = tm.total(4);
   (void)hipEventElapsedTime(&c->stats.ms_total, ev0, ev1);
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-  // 12 B descriptor + ceil(2L/8) B read + ceil(2L/8)+1 B target span per
-  // candidate pair, + 16 B per tuple written
+  // 12 B descriptor + ceil(2L/8) B read + ceil(2L/8)+1 B target span per pair the
+  // launch loads, + 16 B per tuple written.  A launch loads one descriptor, one record and one
+  // span per DESCRIPTOR; a descriptor that stands for two windows is two of the reference's
+  // candidate pairs but is fetched once, so the bytes are billed per descriptor (the r01 figure
+  // billed them per pair and over-credited the kernel).
   const uint64_t L = c->max_len;
-  c->stats.confirm_bytes = c->stats.n_pairs * (12 + (2 * L + 7) / 8 + (2 * L + 7) / 8 + 1) + 16 * c->stats.n_hits;
+  c->stats.confirm_bytes = c->stats.n_descriptors * (12 + (2 * L + 7) / 8 + (2 * L + 7) / 8 + 1) + 16 * c->stats.n_hits;
   if (nhits) *nhits = c->nhits;
   if (!sized && want_pipe) {  // the second batch set gets the capacities the first one ended up with
     if ((rc = ensure(c, c->bs[1].wb, c->bs[0].wb.cap)) || (rc = ensure(c, c->bs[1].rvalid, c->bs[0].rvalid.cap)) ||
@@ -1040,7 +1061,6 @@ int musc_hits_copy_packed(musc_ctx* c, uint64_t* dst, uint64_t capacity, int dst
   if (c->nhits == 0) return 0;
   if (!dst) return fail(c, 2, "musc_hits_copy_packed: dst is NULL");
   HIPCHK(c, hipSetDevice(c->device));
-  if (!c->d_flag) HIPCHK(c, hipMalloc((void**)&c->d_flag, 4));
   uint64_t* out = dst;
   if (!dst_on_device) {
     if ((rc = ensure(c, c->packed, c->nhits))) return rc;
@@ -1120,8 +1140,9 @@ int musc_overflow_probes(musc_ctx* c, uint32_t** read_idx, uint32_t** window, ui
   HIPCHK(c, hipSetDevice(c->device));
   uint64_t cap = 1u << 20;
   for (;;) {
+    TmpBufs B;  // released at the end of every iteration and on every return
     uint2* d_out = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_out, cap * sizeof(uint2)));
+    HIPCHK(c, B.alloc(&d_out, cap * sizeof(uint2)));
     HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8, c->stream));
     const dim3 grid(std::min(nblk(c->nreads, 256), MAX_GRID)), block(256);
     switch (c->rw) {
@@ -1134,19 +1155,14 @@ int musc_overflow_probes(musc_ctx* c, uint32_t** read_idx, uint32_t** window, ui
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_pinned, c->counters + 8, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) {
-      (void)hipFree(d_out);
-      return fail(c, 10, "musc_overflow_probes: %s", hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return fail(c, 10, "musc_overflow_probes: %s", hipGetErrorString(e));
     const uint64_t found = c->h_pinned[0];
     if (found > cap) {  // retry with room for all of them
-      (void)hipFree(d_out);
       cap = found + 16;
       continue;
     }
     std::vector<uint2> h(found ? found : 1);
     if (found) e = hipMemcpy(h.data(), d_out, found * sizeof(uint2), hipMemcpyDeviceToHost);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return fail(c, 10, "musc_overflow_probes: %s", hipGetErrorString(e));
     uint32_t* r = (uint32_t*)malloc(sizeof(uint32_t) * (found ? found : 1));
     uint32_t* w = (uint32_t*)malloc(sizeof(uint32_t) * (found ? found : 1));

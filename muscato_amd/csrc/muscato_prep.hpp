@@ -131,26 +131,7 @@ __global__ void k_prep_pack(const unsigned char* __restrict__ s, const uint64_t*
   if (mv) atomicOr(has_x, 1u);
 }
 
-namespace {
-
-struct PrepBufs {  // everything musc_reads_sort_unique allocates, released on every exit path
-  void* p[16] = {};
-  int n = 0;
-  template <class T>
-  hipError_t alloc(T** out, size_t bytes) {
-    void* q = nullptr;
-    if (n >= 16) return hipErrorOutOfMemory;  // (more allocations than this helper was sized for)
-    const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
-    if (e == hipSuccess) p[n++] = q;
-    *out = (T*)q;
-    return e;
-  }
-  ~PrepBufs() {
-    for (int i = 0; i < n; i++) (void)hipFree(p[i]);
-  }
-};
-
-}  // namespace
+typedef TmpBufs PrepBufs;  // temporaries of musc_reads_sort_unique, released on every exit path
 
 extern "C" int musc_reads_sort_unique(musc_ctx* c, const char* seqs, const uint64_t* offsets, uint64_t nreads,
                                       int on_device, uint32_t** order, uint32_t** ustart, uint64_t* nunique) {
@@ -169,9 +150,9 @@ extern "C" int musc_reads_sort_unique(musc_ctx* c, const char* seqs, const uint6
     if (!*order || !*ustart) return fail(c, 7, "out of host memory");
     return 0;
   }
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0));
-  HIPCHK(c, hipEventCreate(&e1));
+  c->ev_used = 0;
+  hipEvent_t e0 = pool_event(c), e1 = pool_event(c);
+  if (!e0 || !e1) return fail(c, 10, "hipEventCreate failed");
   PrepBufs B;
   const uint64_t n = nreads;
   const unsigned char* d_s = (const unsigned char*)seqs;
@@ -253,8 +234,7 @@ extern "C" int musc_reads_sort_unique(musc_ctx* c, const char* seqs, const uint6
   HIPCHK(c, hipMalloc((void**)&c->rdm, words * 4 + 256));
   HIPCHK(c, hipMemsetAsync(c->rd + words, 0, 256, c->stream));
   HIPCHK(c, hipMemsetAsync(c->rdm + words, 0, 256, c->stream));
-  uint32_t* d_hasx = nullptr;
-  HIPCHK(c, B.alloc(&d_hasx, 4));
+  uint32_t* d_hasx = c->d_flag;
   HIPCHK(c, hipMemsetAsync(d_hasx, 0, 4, c->stream));
   hipLaunchKernelGGL(k_prep_pack, dim3(nblk(words, 256)), dim3(256), 0, c->stream, d_s, d_off, d_uhead, nu, rw, c->rd,
                      c->rdm, d_hasx);
@@ -285,8 +265,6 @@ extern "C" int musc_reads_sort_unique(musc_ctx* c, const char* seqs, const uint6
   }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   c->stats.ms_read_prep = ms;  // device time of the last sort + collapse
   *order = h_order;
   *ustart = h_ustart;

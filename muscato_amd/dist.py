@@ -53,17 +53,22 @@ def gather_hits(local: torch.Tensor, read_base: int, dst: int = 0, group=None) -
 
 
 class HitGatherer:
-    """Streaming form of gather_hits for a sequence of passes (bench.py --gpus N, a service
-    matching batch after batch): one collective per pass, no host round trip, and the gather of
-    pass i runs on the communicator's stream while pass i+1 is being matched.
+    """Streaming gatherv of the tuples of a sequence of passes (bench.py --gpus N, a service
+    matching batch after batch): per pass ONE group of point-to-point transfers -- every rank
+    `isend`s its buffer to rank `dst`, `dst` posts one `irecv` per peer into that peer's slab of a
+    rank-major receive buffer, all of them inside one ncclGroupStart/End (torch's
+    batch_isend_irecv), so the seven incoming transfers of an 8-GPU node run side by side on the
+    seven xGMI links of `dst` instead of one after the other.  No host round trip: the tuple count
+    rides in the last row of the buffer.  The transfer of pass i runs on the communicator's stream
+    while pass i+1 is being matched.
 
-    Every rank owns `depth` send buffers of `cap` + 1 rows; row `cap` carries the tuple count, so
-    no separate exchange of counts is needed.  With `packed=True` a row is one int64 word (the
-    layout of musc_hits_copy_packed: half the bytes on the links; fill() must then write words
-    that already include the shard's read base), otherwise four int32 (read, gene, pos, nmiss).  Rank `dst` owns `depth` sets of receive buffers.
-    submit() fills the next send buffer through `fill(buf_rows) -> n` (e.g. Engine.hits_to),
-    rebases column 0 by `read_base` and starts an asynchronous gather; it first waits for the
-    gather issued `depth` passes earlier, whose buffers it reuses.  finish() waits for
+    Every rank owns `depth` send buffers of `cap` + 1 rows; row `cap` carries the tuple count.  With
+    `packed=True` a row is one int64 word (the layout of musc_hits_copy_packed: half the bytes on
+    the links; fill() must then write words that already include the shard's read base),
+    otherwise four int32 (read, gene, pos, nmiss).  Rank `dst` owns `depth` receive buffers of
+    world x (cap + 1) rows.  submit() fills the next send buffer through `fill(buf_rows) -> n`
+    (e.g. Engine.hits_to), rebases column 0 by `read_base` and starts the transfers; it first
+    waits for the ones issued `depth` passes earlier, whose buffers it reuses.  finish() waits for
     everything; on `dst`, counts(k) / last_result() then give the tuples per rank -- rank-order
     concatenation is the global read order."""
 
@@ -75,8 +80,7 @@ class HitGatherer:
         self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self.recv = None
         if self.rank == dst:
-            self.recv = [[torch.empty(shape, dtype=dtype, device=device) for _ in range(self.world)]
-                         for _ in range(depth)]
+            self.recv = [torch.empty((self.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
         self.work = [None] * depth
         self.i = 0
 
@@ -87,13 +91,17 @@ class HitGatherer:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         return int(int(t.item()) * slack) + 16
 
-    def submit(self, fill, read_base: int) -> int:
-        k = self.i % self.depth
+    def _wait(self, k: int) -> None:
         if self.work[k] is not None:
-            self.work[k].wait()
+            for w in self.work[k]:
+                w.wait()
             if self.send[k].is_cuda:
                 torch.cuda.current_stream().synchronize()  # fill() may write from another stream
             self.work[k] = None
+
+    def submit(self, fill, read_base: int) -> int:
+        k = self.i % self.depth
+        self._wait(k)
         buf = self.send[k]
         n = int(fill(buf))
         if n > self.cap:
@@ -104,21 +112,24 @@ class HitGatherer:
             if read_base and n:
                 buf[:n, 0] += read_base
             buf[self.cap, 0] = n
-        self.work[k] = dist.gather(buf, gather_list=self.recv[k] if self.rank == self.dst else None,
-                                   dst=self.dst, group=self.group, async_op=True)
+        if self.rank == self.dst:
+            self.recv[k][self.rank].copy_(buf)  # the destination's own shard never touches a link
+            ops = [dist.P2POp(dist.irecv, self.recv[k][r], r, self.group) for r in range(self.world) if r != self.dst]
+        else:
+            ops = [dist.P2POp(dist.isend, buf, self.dst, self.group)]
+        self.work[k] = dist.batch_isend_irecv(ops) if ops else []
         self.i += 1
         return n
 
     def counts(self, k: int) -> List[int]:
-        """Tuple counts per rank of buffer set k (rank dst, after its gather completed)."""
-        return [int((b[self.cap] if self.packed else b[self.cap, 0]).item()) for b in self.recv[k]]
+        """Tuple counts per rank of buffer set k (rank dst, after its transfers completed)."""
+        last = self.recv[k][:, self.cap] if self.packed else self.recv[k][:, self.cap, 0]
+        return [int(c) for c in last.tolist()]
 
     def finish(self) -> Optional[List[int]]:
-        """Wait for all outstanding gathers; on dst return the per-rank counts of the last pass."""
+        """Wait for all outstanding transfers; on dst return the per-rank counts of the last pass."""
         for k in range(self.depth):
-            if self.work[k] is not None:
-                self.work[k].wait()
-                self.work[k] = None
+            self._wait(k)
         if self.send[0].is_cuda:
             torch.cuda.current_stream().synchronize()
         if self.rank != self.dst or self.i == 0:
@@ -142,4 +153,4 @@ class HitGatherer:
         if self.rank != self.dst or self.i == 0:
             return None
         k = (self.i - 1) % self.depth
-        return torch.cat([b[:c] for b, c in zip(self.recv[k], self.counts(k))], dim=0)
+        return torch.cat([self.recv[k][r][:c] for r, c in enumerate(self.counts(k))], dim=0)

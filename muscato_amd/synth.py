@@ -37,6 +37,8 @@ class Workload:
     max_matches: int = 1000 * 1000
     match_mode: str = "best"
     revcomp: bool = False  # odd targets are the reverse complements of the even ones (prep_targets -rev)
+    total_raw_reads: int = None  # set when the workload fixes the reads over ALL ranks (strong scaling)
+    seed_key: str = ""           # what the generator seeds are derived from (the WORKLOADS key)
 
     @property
     def n_unique_reads(self) -> int:
@@ -56,6 +58,29 @@ WORKLOADS = {
     "cfg5shard": Workload("cfg5 shard: 25M reads x 5M targets with -rev (10M sequences)", 10_000_000, 1000,
                           25_000_000, 100, (0, 20, 40), 15, 0.97, 3, 5, revcomp=True),
 }
+
+for _k, _w in WORKLOADS.items():
+    _w.seed_key = _k
+
+
+def workload_for(key: str, world: int = 1) -> Workload:
+    """WORKLOADS[key], or the multi-GPU BASELINE configurations whose reads are fixed in total:
+    "cfg4" = BASELINE configs[3], 200 M raw reads x 1 M targets sharded over `world` ranks
+    (25 M per rank at 8), "cfg5" = configs[4], 200 M reads x 5 M targets + reverse complements,
+    Windows 0,20,40, MMTol 3.  Each rank generates its own 200 M / world reads."""
+    if key in WORKLOADS:
+        return WORKLOADS[key]
+    total = 200_000_000
+    per = total // max(world, 1)
+    if key == "cfg4":
+        return Workload("cfg4: 200M reads x 1M targets over %d GPU(s), %dM per rank" % (world, per // 1_000_000),
+                        1_000_000, 1000, per, 100, (0, 20), 15, 0.97, 0, 5, total_raw_reads=per * world, seed_key="cfg4")
+    if key == "cfg5":
+        return Workload("cfg5: 200M reads x 5M targets with -rev (10M sequences) over %d GPU(s), %dM per rank"
+                        % (world, per // 1_000_000), 10_000_000, 1000, per, 100, (0, 20, 40), 15, 0.97, 3, 5,
+                        revcomp=True, total_raw_reads=per * world, seed_key="cfg5")
+    raise KeyError("unknown workload %r (have %s, cfg4, cfg5)" % (key, ", ".join(WORKLOADS)))
+
 
 _ASCII = (65, 67, 71, 84)  # A C G T
 
@@ -98,14 +123,21 @@ def gen_targets(wl: Workload, device, seed: int, copy_frac: float = 0.2, copy_su
 
 
 def gen_unique_reads(wl: Workload, targets_ascii: torch.Tensor, device, seed: int, n_unique: int = None,
-                     sub_rate: float = 0.01, chunk: int = 1_000_000) -> torch.Tensor:
+                     sub_rate: float = 0.01, chunk: int = 1_000_000, return_plan: bool = False):
     """-> uint8 ASCII tensor [U, read_len]: the unique reads the hot path processes
-    (7/9 sampled from targets, 2/9 random), in random order."""
+    (7/9 sampled from targets, 2/9 random), in random order.  With return_plan also the
+    bookkeeping of where each read came from: (reads, {"gene", "off": int64 [U], "mm": uint8 [U]})
+    -- mm = mismatches of the read against its source placement, 255 for the random reads."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     U = wl.n_unique_reads if n_unique is None else n_unique
     L, TL, T = wl.read_len, wl.target_len, wl.n_targets
     out = torch.empty((U, L), dtype=torch.uint8, device=device)
+    plan = None
+    if return_plan:
+        plan = {"gene": torch.empty(U, dtype=torch.int64, device=device),
+                "off": torch.empty(U, dtype=torch.int64, device=device),
+                "mm": torch.empty(U, dtype=torch.uint8, device=device)}
     lut = _lut(device)
     ar = torch.arange(L, device=device)
     flat = targets_ascii.reshape(-1)
@@ -121,7 +153,12 @@ def gen_unique_reads(wl: Workload, targets_ascii: torch.Tensor, device, seed: in
         sub = torch.rand((n, L), device=device, generator=g) < sub_rate
         israndom = torch.rand((n,), device=device, generator=g) < (2.0 / 9.0)
         out[s:e] = torch.where(sub | israndom[:, None], rnd, blk)
-    return out
+        if plan is not None:
+            plan["gene"][s:e] = gi
+            plan["off"][s:e] = off
+            mm = (out[s:e] != blk).sum(dim=1).to(torch.uint8)
+            plan["mm"][s:e] = torch.where(israndom, torch.full_like(mm, 255), mm)
+    return (out, plan) if return_plan else out
 
 
 def sort_reads(reads: torch.Tensor) -> torch.Tensor:

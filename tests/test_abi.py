@@ -38,3 +38,31 @@ def test_init_without_gpu_fails_loudly():
         return
     msg = lib.musc_last_error(None).decode()
     assert "no CPU fallback" in msg or "gfx950" in msg or "HIP" in msg
+
+
+def test_every_entry_point_has_matching_argtypes():
+    """Each prototype of include/muscato_hip.h against the ctypes binding: same number of
+    parameters, pointers bound as pointers, 64-bit integers as 64-bit.  A call through a binding
+    without argtypes passes Python ints as 32-bit C ints: a pointer or a uint64 count is cut to
+    its low half and the library then reads through a wild address on the host (the r01 SIGSEGV
+    inside musc_reads_sort_unique, gpurun_out/t54.log: `offsets[nreads]` read through a
+    truncated pointer).  This check needs no GPU."""
+    import ctypes
+    lib = _lib.load()
+    with open(os.path.join(ROOT, "include", "muscato_hip.h")) as f:
+        hdr = re.sub(r"/\*.*?\*/", " ", f.read(), flags=re.S)
+    protos = re.findall(r"\b(?:int|void|const char\s*\*)\s+(musc_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", hdr)
+    assert {n for n, _ in protos} == set(_lib.SYMBOLS)
+    for name, args in protos:
+        params = [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"]
+        at = getattr(lib, name).argtypes
+        assert at is not None or not params, "%s: argtypes not declared" % name
+        at = list(at or [])
+        assert len(at) == len(params), "%s: %d parameters in the header, %d in the binding" % (name, len(params), len(at))
+        for decl, ct in zip(params, at):
+            is_ptr = "*" in decl
+            bound_ptr = ct is ctypes.c_void_p or ct is ctypes.c_char_p or hasattr(ct, "contents") or \
+                issubclass(ct, ctypes._Pointer)
+            assert is_ptr == bound_ptr, "%s: `%s` bound as %s" % (name, decl, ct)
+            if not is_ptr and "uint64_t" in decl:
+                assert ctypes.sizeof(ct) == 8, "%s: `%s` bound as a %d-byte integer" % (name, decl, ctypes.sizeof(ct))

@@ -1,0 +1,152 @@
+"""The N>1 path end to end on two ranks over gloo: Engine-shaped `fill` callbacks through
+HitGatherer with `n_shards` = world, as bench.py --gpus N and a service would drive it.
+
+CPU (`-m "not gpu"`): the per-shard matcher is a stand-in with the Engine's methods backed by the
+CPU oracle (this container has no GPU); `-m gpu`: two ranks share the one MI355X of the test box,
+each with a real Engine (RCCL refuses two ranks on one device, so the transport stays gloo -- the
+collective calls are the same).  Rank 0's concatenation must equal the single-process result in
+global read order, in the 16-byte and in the packed 8-byte form."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BITS = (16, 12, 16, 8)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleEngine:
+    """The Engine methods the N>1 path uses, on the CPU oracle (tests only)."""
+
+    def __init__(self, ocfg, targets):
+        self.ocfg, self.targets, self.reads, self.hits = ocfg, targets, [], np.zeros((0, 4), np.uint32)
+        self.n_shards_seen = []
+
+    def load_reads(self, reads):
+        self.reads = list(reads)
+        self.n_reads = len(self.reads)
+
+    def match_device(self, cfg, apply_mmtol=True, skip_block_check=False, n_shards=1):
+        from oracle import muscato_oracle as orc
+        assert cfg.to_params(apply_mmtol, skip_block_check, n_shards).n_shards == n_shards
+        self.n_shards_seen.append(n_shards)
+        h = orc.match_direct(self.reads, self.targets, self.ocfg)
+        if apply_mmtol:
+            h = orc.best_filter(h, self.ocfg.MMTol)
+        self.hits = np.array(sorted(h), dtype=np.uint32).reshape(-1, 4)
+        return len(self.hits)
+
+    def hits_to(self, ptr, capacity, on_device):
+        import ctypes
+        assert capacity >= len(self.hits) and not on_device
+        ctypes.memmove(ptr, self.hits.ctypes.data, self.hits.nbytes)
+
+    def hits_to_packed(self, ptr, capacity, on_device, bits, read_base=0):
+        import ctypes
+        h = self.hits.astype(np.uint64)
+        w = ((((h[:, 0] + np.uint64(read_base)) << np.uint64(bits[1]) | h[:, 1]) << np.uint64(bits[2]) | h[:, 2])
+             << np.uint64(bits[3])) | h[:, 3]
+        w = np.ascontiguousarray(w)
+        ctypes.memmove(ptr, w.ctypes.data, w.nbytes)
+
+    def stats(self):
+        return {"n_overflow_blocks": 0}
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, seed, outdir, use_gpu):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cases import make_case
+    from muscato_amd import Config
+    from muscato_amd.dist import HitGatherer, shard_range
+
+    ocfg, reads, targets = make_case(seed)
+    cfg = Config(Windows=list(ocfg.Windows), WindowWidth=ocfg.WindowWidth, PMatch=ocfg.PMatch, MinDinuc=ocfg.MinDinuc,
+                 MaxReadLength=ocfg.MaxReadLength, MaxMatches=ocfg.MaxMatches, MMTol=ocfg.MMTol, MatchMode=ocfg.MatchMode)
+    lo, hi = shard_range(len(reads), rank, world)
+    if use_gpu:
+        from muscato_amd import Engine
+        eng = Engine(0)
+        eng.load_targets(targets)
+    else:
+        eng = OracleEngine(ocfg, targets)
+    eng.load_reads(reads[lo:hi])
+    n0 = eng.match_device(cfg, apply_mmtol=True, n_shards=world)
+    dev = torch.device("cpu")
+    out = {}
+    for packed in (False, True):
+        g = HitGatherer(HitGatherer.agree_capacity(n0, dev), dev, depth=2, packed=packed)
+        for _ in range(3):  # three passes: buffers are reused from the third on
+            n = eng.match_device(cfg, apply_mmtol=True, n_shards=world)
+
+            def fill(buf, n=n):
+                if n and packed:
+                    eng.hits_to_packed(buf.data_ptr(), n, False, BITS, lo)
+                elif n:
+                    eng.hits_to(buf.data_ptr(), n, False)
+                return n
+            g.submit(fill, lo)
+        cn = g.finish()
+        # the MaxMatches proof is per shard: the union holds only if every shard reports 0
+        o = torch.tensor([int(eng.stats()["n_overflow_blocks"])], dtype=torch.int64)
+        dist.all_reduce(o, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            res = g.last_result()
+            out["packed" if packed else "plain"] = (cn, HitGatherer.unpack(res, BITS) if packed else res.to(torch.int64),
+                                                    int(o.item()))
+    if rank == 0:
+        torch.save(out, os.path.join(outdir, "out.pt"))
+    if not use_gpu:
+        assert eng.n_shards_seen and all(s == world for s in eng.n_shards_seen)
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check(tmp_path, seed, use_gpu):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import make_case
+    from oracle import muscato_oracle as orc
+    mp.spawn(_worker, args=(2, _free_port(), seed, str(tmp_path), use_gpu), nprocs=2, join=True)
+    out = torch.load(tmp_path / "out.pt")
+    ocfg, reads, targets = make_case(seed)
+    exp = sorted(orc.best_filter(orc.match_direct(reads, targets, ocfg), ocfg.MMTol))
+    exp = torch.tensor(exp, dtype=torch.int64).reshape(-1, 4)
+    for form in ("plain", "packed"):
+        cn, res, overflow = out[form]
+        assert overflow == 0 and sum(cn) == len(exp)
+        # per-shard tuples come out read-major; order within a read is unspecified
+        idx = np.lexsort((res[:, 3].numpy(), res[:, 2].numpy(), res[:, 1].numpy(), res[:, 0].numpy()))
+        assert torch.equal(res[idx], exp), form
+        assert bool((res[1:, 0] >= res[:-1, 0]).all()), "rank-order concatenation must be in global read order"
+
+
+@pytest.mark.parametrize("seed", [3, 14])
+def test_two_rank_engine_shaped_gather_cpu(tmp_path, seed):
+    _check(tmp_path, seed, use_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 14, 27])
+def test_two_rank_engines_share_one_gpu(tmp_path, seed):
+    _check(tmp_path, seed, use_gpu=True)

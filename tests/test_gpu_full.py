@@ -1,0 +1,187 @@
+"""BASELINE.json configs[2] (cfg3: 50 M reads x 1 M targets) and the per-GPU shard of configs[4]
+(cfg5: 25 M reads x 5 M targets + reverse complements = 10 M sequences / 10 Gbp, Windows 0,20,40,
+MMTol 3) at their own scale on one MI355X.
+
+(a) size-independent properties of the full run -- every tuple is a real placement whose nmiss
+    is the true Hamming distance, the union over windows is a set, planted reads are found at
+    their source, no (window,key) block can have overflowed MaxMatches, best + MMTol keeps exactly
+    the tuples within MMTol of each read's best (cmd/muscato_confirm/main.go:171-250,
+    cmd/muscato_combine_windows/main.go:36-60; `-rev` numbering of
+    cmd/muscato_prep_targets/main.go:48-66 for cfg5);
+(b) a 900 k-read x 100 k-target sample of the same workload, tuple for tuple, against the literal
+    CPU restatement (oracle/literal.cpp).
+
+The reads go through the library's own read prep (musc_reads_sort_unique): the hot path sees the
+distinct sequences in bytewise order, as it does behind reads_sorted.txt.sz."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SAMPLE_READS, SAMPLE_TARGETS = 900_000, 100_000
+
+
+def _log(msg):
+    print("[full] " + msg, flush=True)
+
+
+def _hamming_ok(T_flat, TL, R, h, L, chunk=2_000_000):
+    """every tuple in range, and nmiss == Hamming(read, target[pos:pos+L]) -- on the device"""
+    import torch
+    ar = torch.arange(L, device=h.device)
+    for s in range(0, h.shape[0], chunk):
+        b = h[s:s + chunk]
+        if not bool((b[:, 2] + L <= TL).all()):
+            return False
+        tsub = T_flat[(b[:, 1] * TL + b[:, 2])[:, None] + ar[None, :]]
+        if not bool(((tsub != R[b[:, 0]]).sum(dim=1) == b[:, 3]).all()):
+            return False
+    return True
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5shard"])
+def test_baseline_config_at_full_size(name):
+    import torch
+    from muscato_amd import Config, Engine, sorted_hits, synth
+    from oracle import literal
+    from oracle import muscato_oracle as orc
+
+    wl = synth.WORKLOADS[name]
+    dev = torch.device("cuda", 0)
+    L, TL, NT = wl.read_len, wl.target_len, wl.n_targets
+    budget = int((1.0 - wl.pmatch) * L)
+    seed = synth.SEED_BASE + sum(ord(c) for c in name)
+    cfg = Config(Windows=list(wl.windows), WindowWidth=wl.window_width, PMatch=wl.pmatch, MinDinuc=wl.min_dinuc,
+                 MaxReadLength=L, MaxMatches=wl.max_matches, MMTol=wl.mmtol, MatchMode=wl.match_mode)
+
+    t0 = time.time()
+    T = synth.gen_targets(wl, dev, seed)
+    toff = synth.offsets_for(NT, TL, dev)
+    raw, plan = synth.gen_unique_reads(wl, T, dev, seed + 7919, return_plan=True)
+    nraw = raw.shape[0]
+    roff = synth.offsets_for(nraw, L, dev)
+    torch.cuda.synchronize()
+    _log("%s: %d targets, %d generated reads in %.1fs" % (name, NT, nraw, time.time() - t0))
+
+    eng = Engine(0)
+    try:
+        eng.load_targets_device(T.data_ptr(), toff.data_ptr(), NT)
+        eng.build_index(wl.window_width)
+        order, ustart = eng.sort_unique_reads_arrays(raw.data_ptr(), roff.data_ptr(), nraw, True)
+        U = len(ustart) - 1
+        assert eng.n_reads == U and nraw - U < 0.02 * nraw
+        heads = torch.from_numpy(order[ustart[:-1]].astype(np.int64)).to(dev)
+        del order, ustart
+        R = raw[heads]                          # the distinct reads in the order the library holds them
+        del raw, roff
+        gene, off, mm = plan["gene"][heads], plan["off"][heads], plan["mm"][heads]
+        del plan, heads
+        # the prep sorted them bytewise and collapsed repeats: strictly increasing rows
+        for s in range(0, U - 1, 4_000_000):
+            a, b = R[s:s + 4_000_000], R[s + 1:s + 4_000_001]
+            a = a[:b.shape[0]]
+            d = a != b
+            first = d.to(torch.uint8).argmax(dim=1, keepdim=True)
+            assert bool(d.any(dim=1).all()) and bool((a.gather(1, first) < b.gather(1, first)).all())
+        del a, b, d, first
+
+        # ---- (a) the full run, every accepted tuple (no MMTol)
+        t0 = time.time()
+        n_all = eng.match_device(cfg, apply_mmtol=False)
+        st = eng.stats()
+        _log("%s: %d reads -> %d candidates, %d pairs, %d accepted tuples; device %.2f ms (first pass, %.1fs wall)"
+             % (name, U, st["n_candidates"], st["n_pairs"], n_all, st["ms_total"], time.time() - t0))
+        assert st["n_reads"] == U and st["n_overflow_blocks"] == 0
+        assert st["n_candidates"] >= st["n_pairs"] >= st["n_accepted"] == n_all > 0.5 * U
+        h32 = torch.empty((n_all, 4), dtype=torch.int32, device=dev)
+        eng.hits_to(h32.data_ptr(), n_all, True)
+        h = h32.to(torch.int64)
+        del h32
+        assert bool((h[:, 0] < U).all()) and bool((h[:, 1] < NT).all()) and bool((h[:, 3] <= budget).all())
+        assert _hamming_ok(T.reshape(-1), TL, R, h, L), "a tuple is not a real placement / nmiss is not the Hamming distance"
+        key = (h[:, 0] << 34) | (h[:, 1] << 10) | h[:, 2]   # 26 + 24 + 10 bits (gene < 2^24, pos < 2^10)
+        assert NT < (1 << 24) and TL <= (1 << 10) and U < (1 << 26)
+        skey = torch.sort(key).values
+        assert bool((skey[1:] != skey[:-1]).all()), "the union over windows is not a set"
+        # planted reads: one that matches its source verbatim (not at target position 0, where the
+        # literal-100 rule blinds window 0 for reads longer than 100 - ww) must be reported there
+        # with nmiss 0 unless none of its windows passes the MinDinuc gate
+        must = (mm == 0) & (off != 0)
+        want = (torch.arange(U, device=dev) << 34) | (gene << 10) | off
+        pos_in = torch.searchsorted(skey, want).clamp(max=skey.shape[0] - 1)
+        found = skey[pos_in] == want
+        missing = torch.nonzero(must & ~found).reshape(-1)
+        assert int(missing.shape[0]) < 0.01 * int(must.sum())
+        ocfg = orc.Config(Windows=list(wl.windows), WindowWidth=wl.window_width, MinDinuc=wl.min_dinuc, MaxReadLength=L)
+        for m in missing[:200].tolist():
+            r = bytes(R[m].cpu().numpy())
+            assert not any(orc.window_valid(r, k, ocfg) for k in range(len(wl.windows))), \
+                "a planted read with a usable window was not found"
+        # a planted read within budget is reported at its source with its true distance whenever found
+        within = (mm <= budget) & found
+        assert int(within.sum()) > 0.6 * U
+        del want, pos_in, found, must, missing, within
+
+        # best + MMTol: exactly the tuples within MMTol of the read's best
+        bmin = torch.full((U,), 255, dtype=torch.int64, device=dev)
+        bmin.scatter_reduce_(0, h[:, 0], h[:, 3], reduce="amin")
+        keep = h[:, 3] <= bmin[h[:, 0]] + wl.mmtol
+        exp_keys = torch.sort(key[keep]).values
+        del keep, bmin, key, skey, h
+        n_best = eng.match_device(cfg, apply_mmtol=True)
+        st2 = eng.stats()
+        assert st2["n_overflow_blocks"] == 0
+        b32 = torch.empty((n_best, 4), dtype=torch.int32, device=dev)
+        eng.hits_to(b32.data_ptr(), n_best, True)
+        b = b32.to(torch.int64)
+        got_keys = torch.sort((b[:, 0] << 34) | (b[:, 1] << 10) | b[:, 2]).values
+        assert got_keys.shape == exp_keys.shape and bool((got_keys == exp_keys).all()), "best+MMTol set differs"
+        del b32, b, got_keys, exp_keys
+        # idempotence (this pass is "sized": no host round trips)
+        assert eng.match_device(cfg, apply_mmtol=True) == n_best
+        _log("%s: %d tuples after best+MMTol(%d); sized pass %.2f ms on the device"
+             % (name, n_best, wl.mmtol, eng.stats()["ms_total"]))
+
+        # ---- (b) the sample against the literal oracle: the reads planted in the first
+        # SAMPLE_TARGETS targets (so that most of the sample has something to find) topped up with
+        # evenly spaced others, in the library's order (still distinct and bytewise sorted)
+        nt = min(NT, SAMPLE_TARGETS)
+        planted = torch.nonzero((gene < nt) & (mm != 255)).reshape(-1)[:2 * SAMPLE_READS // 3]
+        stride = max(1, U // (SAMPLE_READS - planted.shape[0]))
+        pick = torch.zeros(U, dtype=torch.bool, device=dev)
+        pick[planted] = True
+        pick[::stride] = True
+        idx = torch.nonzero(pick).reshape(-1)[:SAMPLE_READS]
+        Rs = R[idx].contiguous()
+        ns = Rs.shape[0]
+        rbuf = np.concatenate([Rs.reshape(-1).cpu().numpy(), np.zeros(8, np.uint8)])
+        gbuf = np.concatenate([T[:nt].reshape(-1).cpu().numpy(), np.zeros(8, np.uint8)])
+        rso = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
+        gso = np.arange(nt + 1, dtype=np.uint64) * np.uint64(TL)
+        del planted, pick, idx
+    finally:
+        eng.close()
+    del R, T, Rs, gene, off, mm
+    torch.cuda.empty_cache()
+
+    class OC:
+        Windows = list(wl.windows); WindowWidth = wl.window_width; PMatch = wl.pmatch
+        MinDinuc = wl.min_dinuc; MaxReadLength = L; MaxMatches = wl.max_matches; MatchMode = wl.match_mode
+    t0 = time.time()
+    exp, _, _ = literal.match_arrays(rbuf, rso, gbuf, gso,
+                                     literal.make_params(OC, bloom_size=400_000_000, num_hash=20, nthreads=16))
+    _log("%s: literal oracle on %d reads x %d targets: %d tuples in %.1fs" % (name, ns, nt, len(exp), time.time() - t0))
+    assert len(exp) > 0.1 * ns
+    with Engine(0) as e2:
+        e2.load_targets_arrays(gbuf, gso)
+        e2.load_reads_arrays(rbuf, rso)
+        got = sorted_hits(e2.match(cfg, apply_mmtol=False))
+        assert e2.stats()["n_overflow_blocks"] == 0
+        assert got.shape == exp.shape and (got == exp).all(), "GPU tuples differ from the literal oracle on the sample"
+        bestg = sorted_hits(e2.match(cfg, apply_mmtol=True))
+    bmin = np.full(ns, 255, dtype=np.int64)
+    np.minimum.at(bmin, exp[:, 0], exp[:, 3].astype(np.int64))
+    bexp = exp[exp[:, 3] <= bmin[exp[:, 0]] + wl.mmtol]
+    assert bestg.shape == bexp.shape and (bestg == bexp).all(), "best+MMTol differs from the oracle on the sample"

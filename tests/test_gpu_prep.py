@@ -86,6 +86,18 @@ def test_sort_unique_edge_cases(eng):
     check_groups(reads, order, ustart)
 
 
+def test_sort_unique_empty_reads_and_ragged_counts(eng):
+    """All-empty reads (maxlen 0: one key word of zeros), and read counts that are not a multiple
+    of the 256-thread block on either side of it."""
+    order, ustart = eng.sort_unique_reads([b""] * 5)
+    assert order.tolist() == [0, 1, 2, 3, 4] and ustart.tolist() == [0, 5] and eng.n_reads == 1
+    rng = random.Random(99)
+    for n in (255, 256, 257, 70001):
+        reads = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 30))) for _ in range(n)]
+        order, ustart = eng.sort_unique_reads(reads)
+        check_groups(reads, order, ustart)
+
+
 @pytest.mark.parametrize("seed", [1, 9, 30])
 def test_prepared_reads_give_the_same_hits(eng, seed):
     """Loading through the GPU prep == loading the sorted unique reads directly."""
