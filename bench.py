@@ -167,10 +167,14 @@ def main() -> int:
     ap.add_argument("--no-survey-scope", action="store_true", help="skip the pinned-host-to-pinned-host leg")
     ap.add_argument("--unsorted", action="store_true", help="leave the unique reads in random order")
     ap.add_argument("--no-block-check", action="store_true", help="skip the MaxMatches per-block overflow check")
+    ap.add_argument("--index", choices=["auto", "classic"], default="auto",
+                    help="classic: force the 64-byte-bucket index and the two-kernel path (MUSC_INDEX=classic)")
     ap.add_argument("--xrate", type=float, default=0.0,
                     help="fraction of bases replaced by X in targets and reads (the correctness/timing run with the mask planes)")
     args = ap.parse_args()
 
+    if args.index == "classic":
+        os.environ["MUSC_INDEX"] = "classic"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -236,7 +240,7 @@ def main() -> int:
     eng.load_targets_device(targets.data_ptr(), toff.data_ptr(), wl.n_targets)
     t_dbload = time.time() - t0
     t0 = time.time()
-    eng.build_index(wl.window_width)
+    eng.build_index_for(cfg, wl.read_len)  # the index the match will pick (context buckets when the run fits them)
     t_index = time.time() - t0
     ms_index = eng.stats()["ms_index_build"]
     log("db pack %.3fs, index build %.3fs (device %.1f ms)" % (t_dbload, t_index, ms_index))
@@ -366,7 +370,8 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     acc = {"ms_confirm": 0.0, "launches": 0, "bytes": 0, "ms_screen": 0.0, "ms_scan": 0.0,
-           "ms_select": 0.0, "ms_total": 0.0, "screen_launches": 0}
+           "ms_select": 0.0, "ms_total": 0.0, "screen_launches": 0, "match_launches": 0, "match_bytes": 0,
+           "match_bytes_strict": 0}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -374,6 +379,8 @@ def main() -> int:
         st = eng.stats()  # host-side read of numbers the library already holds
         acc["ms_confirm"] += st["ms_confirm"]; acc["launches"] += st["confirm_launches"]
         acc["bytes"] += st["confirm_bytes"]; acc["screen_launches"] += st["n_batches"]
+        for k in ("match_launches", "match_bytes", "match_bytes_strict"):
+            acc[k] += st[k]
         for k in ("ms_screen", "ms_scan", "ms_select", "ms_total"):
             acc[k] += st[k]
     if gatherer is not None:
@@ -502,6 +509,36 @@ def main() -> int:
             "entries_per_launch": st["n_candidates"] / sl, "avg_launch_ms": ms_scr, "launches_per_step": st["n_batches"],
         }
         dominant = screen_roof if acc["ms_screen"] >= acc["ms_confirm"] else confirm_roof
+        kind = st["index_kind"]
+        match_roof = None
+        if kind == 1:
+            # k_match (context buckets): screen + confirm + select in one kernel.  A launch loads every
+            # read's record, ONE 128-byte bucket line per (read, window) probe -- the line carries the
+            # placements' target bases, there is no target gather -- the overflow entries it walks, and
+            # stages the tuples.
+            mlc = max(acc["match_launches"], 1)
+            ms_m = acc["ms_screen"] / mlc
+            b_m, b_s = acc["match_bytes"] / mlc, acc["match_bytes_strict"] / mlc
+            ach = (b_m / 1e9) / (ms_m / 1e3) if ms_m > 0 else 0.0
+            ach_s = (b_s / 1e9) / (ms_m / 1e3) if ms_m > 0 else 0.0
+            nlm = max(st["match_launches"], 1)
+            match_roof = {
+                "kernel": "k_match (screen + confirm + per-read selection, context buckets)", "bound": "hbm",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
+                "traffic": measured_traffic(args.workload, "k_match") if not args.reads else None,
+                "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc passes of this command, recorded; not measured by this run)",
+                "algorithmic_bytes": "%d B per read record + 128 B bucket line per probe + 40 B per overflow entry walked + "
+                                     "16 B per tuple staged" % rec_b,
+                "bytes_per_launch": b_m,
+                "achieved_strict": ach_s, "frac_strict": ach_s / HBM_PEAK_GBS,
+                "strict_note": "a probe billed only for what it uses of its line: 8 B header + 40 B per index entry present",
+                "reads_per_launch": st["n_reads"] / nlm, "probes_per_launch": st["n_read_windows"] / nlm,
+                "entries_per_launch": st["n_candidates"] / nlm, "overflow_entries_per_launch": st["n_overflow_entries"] / nlm,
+                "compared_per_launch": st["n_pairs"] / nlm, "tuples_per_launch": st["n_hits"] / nlm,
+                "avg_launch_ms": ms_m, "launches_per_step": st["match_launches"],
+            }
+            dominant, confirm_roof, screen_roof = match_roof, None, None
         res = {
             "metric": "reads/sec (100 bp, multi-map) at 1/2/4/8 MI355X; confirm-kernel HBM GB/s vs peak",  # BASELINE.json's wording: value = reads/sec, the kernels are under "roofline*"
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -520,11 +557,14 @@ def main() -> int:
                                 + ", repeat passes over the same reads (no sizing round trips); SURVEY 8d's "
                                   "pinned-host-to-pinned-host scope is `survey_scope`, a pass over fresh reads `first_pass_ms`",
             },
+            "index": {"kind": "context buckets (128 B, fused k_match)" if kind == 1 else "64-byte buckets (k_screen -> k_confirm)",
+                      "bytes": st["index_bytes"]},
             "roofline": dominant, "roofline_confirm": confirm_roof, "roofline_screen": screen_roof,
             "per_step": {
                 "candidates": st["n_candidates"], "pairs": st["n_pairs"], "descriptors": st["n_descriptors"],
                 "accepted": st["n_accepted"], "hits": st["n_hits"],
                 "hits_on_rank0": gathered_n[0], "maxmatches_overflow_blocks": overflow_seen[0], "read_windows": st["n_read_windows"],
+                "overflow_entries": st["n_overflow_entries"],
                 "ms_screen": acc["ms_screen"] / args.steps, "ms_scan": acc["ms_scan"] / args.steps,
                 "ms_confirm": acc["ms_confirm"] / args.steps,
                 "ms_select": acc["ms_select"] / args.steps, "ms_device_total": acc["ms_total"] / args.steps,

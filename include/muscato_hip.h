@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MUSC_ABI_VERSION 1
+#define MUSC_ABI_VERSION 2
 #define MUSC_MAX_WINDOWS 16
 
 typedef struct musc_ctx musc_ctx;
@@ -99,7 +99,8 @@ typedef struct {
   uint32_t confirm_launches;
   uint32_t n_batches;
   float ms_screen;          /* HIP-event time of each kernel family, summed over batches:  */
-  float ms_scan;            /*   k_screen | scan | (unused) | k_confirm | scan+k_compact   */
+  float ms_scan;            /*   k_screen (index_kind 0) or k_match (1) | scan | (unused) |
+                             *   k_confirm (index_kind 0 only) | scan+k_compact            */
   float ms_unused0;
   float ms_confirm;
   float ms_select;
@@ -107,7 +108,19 @@ typedef struct {
   float ms_index_build;     /* last musc_db_build_index                                 */
   float ms_read_prep;       /* last musc_reads_sort_unique (device time)                   */
   uint64_t n_descriptors;   /* descriptors k_screen wrote: one per placement of a read, also
-                             * when two windows of the read found it (then it is two pairs) */
+                             * when two windows of the read found it (then it is two pairs);
+                             * 0 with context buckets (no descriptors exist)               */
+  /* ---- since ABI version 2 */
+  uint32_t index_kind;      /* index the pass ran on: 0 = 64-byte buckets + target gather
+                             * (k_screen -> k_confirm), 1 = context buckets (k_match)       */
+  uint32_t match_launches;  /* k_match launches (index_kind 1)                              */
+  uint64_t n_overflow_entries; /* index entries beyond a bucket's inline ones that were walked */
+  uint64_t match_bytes;     /* algorithmic bytes of the k_match launches: record (ceil(2L/8) B)
+                             * per read + one 128-B bucket line per probe + 40 B per overflow
+                             * entry walked + 16 B per tuple staged                         */
+  uint64_t match_bytes_strict; /* the same with a probe billed for what it uses of its line:
+                             * 8 B header + 40 B per inline entry present                   */
+  uint64_t index_bytes;     /* device memory held by the index (table + overflow entries)  */
 } musc_stats;
 
 int musc_abi_version(void);
@@ -137,6 +150,14 @@ int musc_db_load_packed(musc_ctx* ctx, const uint8_t* bases2bit, const uint8_t* 
  * database scan of cmd/muscato_screen/main.go:116-207, 256-366 (result-equivalent: SURVEY.md
  * 8a note H). */
 int musc_db_build_index(musc_ctx* ctx, int32_t window_width);
+/* The same for a whole parameter block: builds the index musc_match* will pick for `params` and
+ * reads of at most max_read_len bases (0 = params->max_read_length) -- context buckets (128-byte
+ * buckets that carry each placement's 120 surrounding target bases, so that screen and confirm
+ * are one kernel and no target gather is needed; see kernels_match.hpp) when the run fits them,
+ * the 64-byte-bucket index of musc_db_build_index otherwise.  musc_match* does this lazily;
+ * calling it first only moves the one-off cost out of the first match.  MUSC_INDEX=classic in
+ * the environment forces the 64-byte-bucket index. */
+int musc_db_build_index_for(musc_ctx* ctx, const musc_params* params, int32_t max_read_len);
 
 /* ---- reads: replaces reading reads_sorted.txt.sz (cmd/muscato_screen/main.go:120-191,
  * cmd/muscato_window_reads/main.go:94-141).  Reads must already be prepared as the

@@ -46,13 +46,16 @@ class MuscStats(ctypes.Structure):
         ("ms_confirm", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_total", ctypes.c_float),
         ("ms_index_build", ctypes.c_float), ("ms_read_prep", ctypes.c_float),
         ("n_descriptors", ctypes.c_uint64),
+        ("index_kind", ctypes.c_uint32), ("match_launches", ctypes.c_uint32),
+        ("n_overflow_entries", ctypes.c_uint64), ("match_bytes", ctypes.c_uint64),
+        ("match_bytes_strict", ctypes.c_uint64), ("index_bytes", ctypes.c_uint64),
     ]
 
 
 # every symbol include/muscato_hip.h declares
 SYMBOLS = [
     "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error",
-    "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
+    "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for",
     "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique",
     "musc_match_device", "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_unpack", "musc_match", "musc_free_hits",
     "musc_get_stats", "musc_gather", "musc_overflow_probes", "musc_free_u32",
@@ -84,6 +87,7 @@ def load() -> ctypes.CDLL:
     lib.musc_db_load_ascii.argtypes = [vp, vp, vp, ctypes.c_uint32, ctypes.c_int]
     lib.musc_db_load_packed.argtypes = [vp, vp, vp, vp, ctypes.c_uint32]
     lib.musc_db_build_index.argtypes = [vp, i32]
+    lib.musc_db_build_index_for.argtypes = [vp, ctypes.POINTER(MuscParams), i32]
     lib.musc_reads_load_ascii.argtypes = [vp, vp, vp, u64, ctypes.c_int]
     lib.musc_reads_load_packed.argtypes = [vp, vp, vp, vp, u64]
     lib.musc_reads_sort_unique.argtypes = [vp, vp, vp, u64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
@@ -102,7 +106,7 @@ def load() -> ctypes.CDLL:
     lib.musc_free_u32.restype = None
     lib.musc_gather.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(u64),
                                 ctypes.POINTER(vp), ctypes.POINTER(u64)]
-    for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index",
+    for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for", "musc_db_build_index_for",
                  "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique", "musc_match_device",
                  "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_unpack", "musc_match", "musc_get_stats",
                  "musc_gather"):

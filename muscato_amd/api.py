@@ -203,6 +203,12 @@ class Engine:
     def build_index(self, window_width: int) -> None:
         self._check(self._lib.musc_db_build_index(self._h, int(window_width)), "musc_db_build_index")
 
+    def build_index_for(self, cfg: "Config", max_read_len: int = 0) -> None:
+        """Build the index match() will pick for `cfg` (context buckets when the run fits them)."""
+        p = cfg.to_params(True)
+        self._check(self._lib.musc_db_build_index_for(self._h, ctypes.byref(p), int(max_read_len)),
+                    "musc_db_build_index_for")
+
     # ---- reads (already prepared: X-substituted, truncated, unique)
     def load_reads(self, seqs: Sequence[bytes]) -> None:
         buf, off = concat(seqs)

@@ -35,6 +35,7 @@
 #include "kernels_index.hpp"
 #include "kernels_screen.hpp"
 #include "kernels_confirm.hpp"
+#include "kernels_match.hpp"
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -101,6 +102,16 @@ struct musc_ctx {
                                           // hipMalloc / hipFree of tens of GiB take seconds)
   uint64_t idx_n = 0;       // indexed window starts
   uint64_t idx_novf = 0;
+  // index kind 1: context buckets (kernels_match.hpp); only one kind is resident at a time
+  int idx_kind = 0;         // of the index idx_ww describes: 0 = Bucket table, 1 = CtxBucket table
+  int idx_CL = 0;           // context buckets: bases of left context (the largest window start)
+  CtxBucket* ctx_T = nullptr;
+  CtxEntry* ctx_E = nullptr;
+  uint64_t ctx_T_cap = 0, ctx_E_cap = 0;
+  MatchParams* d_mp = nullptr;  // k_match's parameter block
+  MatchParams h_mp;             // what d_mp holds
+  bool h_mp_valid = false;
+  DevBuf<uint4> spill;          // k_match: reported candidates beyond a tile's LDS list
 
   // reads
   uint32_t* rd = nullptr;
@@ -257,6 +268,15 @@ void free_index(musc_ctx* c) {
   c->idx_ww = 0;
   c->idx_n = 0;
   c->data_epoch++;
+}
+
+// release the context-bucket tables (the classic index is being built, or the database changes)
+void drop_ctx_index(musc_ctx* c) {
+  if (c->ctx_T) (void)hipFree(c->ctx_T);
+  if (c->ctx_E) (void)hipFree(c->ctx_E);
+  c->ctx_T = nullptr;
+  c->ctx_E = nullptr;
+  c->ctx_T_cap = c->ctx_E_cap = 0;
 }
 
 void free_db(musc_ctx* c) {
@@ -416,6 +436,7 @@ int musc_init(int device_ordinal, musc_ctx** out) {
       (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
       (e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc((void**)&c->d_flag, 4)) != hipSuccess ||
+      (e = hipMalloc((void**)&c->d_mp, sizeof(MatchParams))) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(uint64_t))) != hipSuccess) {
     fail(nullptr, 3, "musc_init: %s", hipGetErrorString(e));
     musc_destroy(c);
@@ -438,6 +459,10 @@ void musc_destroy(musc_ctx* c) {
   free_reads(c);
   if (c->idx_T) (void)hipFree(c->idx_T);
   if (c->idx_E) (void)hipFree(c->idx_E);
+  if (c->ctx_T) (void)hipFree(c->ctx_T);
+  if (c->ctx_E) (void)hipFree(c->ctx_E);
+  if (c->d_mp) (void)hipFree(c->d_mp);
+  c->spill.release();
   for (int i = 0; i < 2; i++) {
     c->bs[i].wb.release(); c->bs[i].tbase.release(); c->bs[i].rvalid.release(); c->bs[i].tcount.release();
     c->bs[i].cdesc.release();
@@ -568,8 +593,10 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   if (!c->db2) return fail(c, 4, "no database loaded");
   if (ww < 1 || ww > 4096) return fail(c, 2, "bad window width %d", ww);
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->idx_ww == ww && c->idx_T) return 0;
+  if (c->idx_ww == ww && c->idx_kind == 0 && c->idx_T) return 0;
   free_index(c);
+  drop_ctx_index(c);  // one index kind is resident at a time
+  c->idx_kind = 0;
   c->wide = c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE") != nullptr;
   if (c->wide && c->nseq >= (1u << 24))
     return fail(c, 5, "a database of 2^32 bases or more may hold at most 2^24 targets (has %u)", c->nseq);
@@ -651,6 +678,162 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   c->idx_bits = bits;
   c->idx_direct = direct;
   return 0;
+}
+
+// Context buckets for window width ww and CL bases of left context (kernels_match.hpp).
+// Returns 0 and leaves idx_kind == 1 on success; 100 when the table does not fit the device's
+// free memory (the caller then builds the classic index); anything else is an error.
+static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
+  if (c->idx_kind == 1 && c->idx_ww == ww && c->idx_CL == CL && c->ctx_T) return 0;
+  free_index(c);
+  c->wide = 0;
+  // 4^ww buckets with the key as the bucket (exact) when that is at most twice the database's
+  // window count; else about one bucket per base under a 64-bit mix (a colliding key fails the
+  // window comparison in k_match: the context includes the window bases)
+  int bits, direct = 0;
+  const uint64_t floor_bases = std::max<uint64_t>(c->nbases, 1ull << 9);
+  if (2 * ww <= 30 && (1ull << (2 * ww)) <= 2 * floor_bases) {
+    bits = 2 * ww;
+    direct = 1;
+  } else {
+    bits = 10;
+    while (bits < 30 && (1ull << bits) < c->nbases) bits++;
+  }
+  if (const char* ov = getenv("MUSC_DEBUG_INDEX_BITS")) {  // experiments only: force a hashed table size
+    const int v = atoi(ov);
+    if (v >= 8 && v <= 30) { bits = v; direct = 0; }
+  }
+  const uint64_t nb = 1ull << bits;
+  // memory: the table, 8 B + 4 B per bucket of build temporaries, and the overflow entries (their
+  // number is known only after the counting pass: assume a third of the windows for the estimate)
+  {
+    size_t mfree = 0, mtotal = 0;
+    HIPCHK(c, hipMemGetInfo(&mfree, &mtotal));
+    const uint64_t have = (uint64_t)mfree + (c->ctx_T ? c->ctx_T_cap * sizeof(CtxBucket) : 0) +
+                          (c->ctx_E ? c->ctx_E_cap * sizeof(CtxEntry) : 0) + (c->idx_T ? c->idx_T_cap * sizeof(Bucket) : 0) +
+                          (c->idx_E ? c->idx_E_cap * sizeof(uint4) : 0);
+    const uint64_t need = (nb + 1) * (sizeof(CtxBucket) + 12) + c->nbases / 3 * sizeof(CtxEntry) + (4ull << 30);
+    if (need > have) return 100;
+  }
+  // the classic tables go first (one index kind is resident at a time)
+  if (c->idx_T) (void)hipFree(c->idx_T);
+  if (c->idx_E) (void)hipFree(c->idx_E);
+  c->idx_T = nullptr;
+  c->idx_E = nullptr;
+  c->idx_T_cap = c->idx_E_cap = 0;
+  c->ev_used = 0;
+  hipEvent_t e0 = pool_event(c), e1 = pool_event(c), e2 = pool_event(c), e3 = pool_event(c);
+  if (!e0 || !e1 || !e2 || !e3) return fail(c, 10, "hipEventCreate failed");
+  if (c->ctx_T_cap < nb + 1) {
+    if (c->ctx_T) (void)hipFree(c->ctx_T);
+    c->ctx_T = nullptr;
+    c->ctx_T_cap = 0;
+    if (hipMalloc((void**)&c->ctx_T, (nb + 1) * sizeof(CtxBucket)) != hipSuccess) {
+      (void)hipGetLastError();
+      c->ctx_T = nullptr;
+      return 100;
+    }
+    c->ctx_T_cap = nb + 1;
+  }
+  TmpBufs B;
+  uint64_t *tmp = nullptr, *stmp = nullptr;
+  uint32_t* cursor = nullptr;
+  if (B.alloc(&tmp, (nb + 1 + 16) * 8) != hipSuccess || B.alloc(&stmp, scan_tmp_elems(nb + 1) * 8) != hipSuccess ||
+      B.alloc(&cursor, (nb + 1) * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    return 100;
+  }
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->ctx_T, 0, (nb + 1) * sizeof(CtxBucket), c->stream));
+  HIPCHK(c, hipMemsetAsync(cursor, 0, (nb + 1) * 4, c->stream));
+  const unsigned blocks = (unsigned)std::min<uint64_t>((c->nbases + 255) / 256, 1u << 22);
+  if (c->nbases) {
+    hipLaunchKernelGGL(k_index_ctx<false>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+                       ww, bits, direct, CL, c->ctx_T, (CtxEntry*)nullptr, cursor);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_ctx_ovf_count, dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, c->ctx_T, nb, tmp);
+  HIPCHK(c, hipGetLastError());
+  int rc = scan_u64(c, tmp, tmp, nb + 1, stmp);
+  if (rc) return rc;
+  uint64_t novf = 0;
+  HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 8, hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_ctx_ovf_set, dim3(nblk(nb, 256)), dim3(256), 0, c->stream, c->ctx_T, nb, tmp);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(e2, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (novf >= 0xFFFFFFF0ull) return fail(c, 5, "internal: %llu overflow entries do not fit 32-bit offsets", (unsigned long long)novf);
+  c->idx_novf = novf;
+  if (c->ctx_E_cap < novf + 16) {
+    if (c->ctx_E) (void)hipFree(c->ctx_E);
+    c->ctx_E = nullptr;
+    c->ctx_E_cap = 0;
+    if (hipMalloc((void**)&c->ctx_E, (novf + 16) * sizeof(CtxEntry)) != hipSuccess) {
+      (void)hipGetLastError();
+      c->ctx_E = nullptr;
+      return 100;
+    }
+    c->ctx_E_cap = novf + 16;
+  }
+  HIPCHK(c, hipEventRecord(e3, c->stream));
+  if (c->nbases) {
+    hipLaunchKernelGGL(k_index_ctx<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+                       ww, bits, direct, CL, c->ctx_T, c->ctx_E, cursor);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0, ms2 = 0;
+  (void)hipEventElapsedTime(&ms, e0, e2);
+  (void)hipEventElapsedTime(&ms2, e3, e1);
+  c->stats.ms_index_build = ms + ms2;
+  c->idx_kind = 1;
+  c->idx_ww = ww;
+  c->idx_CL = CL;
+  c->idx_bits = bits;
+  c->idx_direct = direct;
+  return 0;
+}
+
+// Which index a run with these parameters and reads of at most max_len bases uses: context
+// buckets when every read fits their 120 bases of context around each of at most CTX_MAX_W
+// windows, nothing holds an X (the context has no mask plane) and positions fit 32 bits.
+static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL) {
+  if (const char* e = getenv("MUSC_INDEX"))
+    if (strcmp(e, "classic") == 0) return false;
+  if (c->dbm2 || c->rdm) return false;
+  if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
+  if (P->n_windows > CTX_MAX_W) return false;
+  int q1min = P->windows[0], q1max = P->windows[0];
+  for (int k = 1; k < P->n_windows; k++) {
+    q1min = std::min(q1min, P->windows[k]);
+    q1max = std::max(q1max, P->windows[k]);
+  }
+  if ((int64_t)q1max - q1min + (int64_t)max_len > CTX_BASES) return false;
+  if (q1max > CTX_BASES) return false;
+  *CL = q1max;
+  return true;
+}
+
+static int ensure_index(musc_ctx* c, const musc_params* P, uint32_t max_len) {
+  int CL = 0;
+  if (ctx_eligible(c, P, max_len, &CL)) {
+    const int rc = build_index_ctx(c, P->window_width, CL);
+    if (rc != 100) return rc;
+    // (does not fit the free memory: the classic index is a quarter of the size)
+  }
+  return musc_db_build_index(c, P->window_width);
+}
+
+int musc_db_build_index_for(musc_ctx* c, const musc_params* P, int32_t max_read_len) {
+  if (!c) return 1;
+  int rc = check_params(c, P);
+  if (rc) return rc;
+  if (!c->db2) return fail(c, 4, "no database loaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t ml = max_read_len > 0 ? (uint32_t)max_read_len
+                                       : (P->max_read_length > 0 ? (uint32_t)P->max_read_length : c->max_len);
+  return ensure_index(c, P, ml);
 }
 
 // ---------------------------------------------------------------- reads
@@ -747,6 +930,175 @@ int musc_reads_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t*
 
 // ---------------------------------------------------------------- hot path
 
+// One pass on context buckets: per batch k_match (screen + confirm + select, tuples staged per
+// workgroup) -> scan of the per-tile tuple counts -> k_compact.  The only data-dependent
+// capacities are the staging region and the spill region of a workgroup; the first pass over a
+// (reads, database, parameters) combination sizes them (a batch that does not fit makes the pass
+// start over with larger buffers), later passes run without host round trips and check the
+// guards once at the end -- the same protocol as the two-kernel path below.
+extern "C++" {
+template <int RW>
+static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr) {
+  const dim3 grid(std::min(nblk(n, TILE), MAX_GRID)), block(TILE);
+  const size_t lds = block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;
+#define MUSC_LAUNCH_MATCH(W2)                                                                                     \
+  hipLaunchKernelGGL((k_match<RW, W2>), grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,       \
+                     c->ctx_T, c->ctx_E, c->stage.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,    \
+                     c->tcount2.p, block_mode, block_thr, c->block_table.p, c->counters)
+  if (w2) MUSC_LAUNCH_MATCH(true); else MUSC_LAUNCH_MATCH(false);
+#undef MUSC_LAUNCH_MATCH
+}
+}  // extern "C++"
+
+static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& pp, int block_mode, uint32_t block_thr,
+                          uint64_t max_matches, uint64_t planned_batches, uint64_t* nhits) {
+  int rc = 0;
+  if (c->rw != 4 && c->rw != 8 && c->rw != 12) return fail(c, 12, "internal: record stride %d on the context path", c->rw);
+  {
+    MatchParams mp;
+    memset(&mp, 0, sizeof mp);
+    mp.W = pp.W; mp.ww = pp.ww; mp.min_dinuc = pp.min_dinuc; mp.bits = pp.bits; mp.direct = pp.direct;
+    mp.mmtol = pp.mmtol; mp.apply_mmtol = pp.apply_mmtol; mp.max_len = pp.max_len; mp.CL = c->idx_CL;
+    mp.q1zero_mask = pp.q1zero_mask;
+    for (int k = 0; k < pp.W && k < CTX_MAX_W; k++) mp.win[k] = pp.win[k];
+    if (!c->h_mp_valid || memcmp(&mp, &c->h_mp, sizeof mp) != 0) {
+      c->h_mp = mp;
+      HIPCHK(c, hipMemcpyAsync(c->d_mp, &c->h_mp, sizeof mp, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->h_mp_valid = true;
+    }
+  }
+  const bool check_blocks = block_mode != 0;
+  const bool sized = c->sized_epoch == c->data_epoch && c->sized_exact_blocks == (block_mode == 2) &&
+                     memcmp(&c->sized_params, P, sizeof *P) == 0 && !getenv("MUSC_DEBUG_SYNC");
+  uint32_t bsz = sized ? c->sized_bsz : c->batch_reads;
+  const uint64_t L = c->max_len;
+  for (int attempt = 0;; attempt++) {
+    if (attempt > 40) return fail(c, 12, "internal: the context pass did not converge on buffer sizes");
+    Timer tm(c);
+    hipEvent_t ev0 = pool_event(c), ev1 = pool_event(c);
+    if (!ev0 || !ev1) return fail(c, 10, "hipEventCreate failed");
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    if (block_mode == 2) HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
+    HIPCHK(c, hipEventRecord(ev0, c->stream));
+    uint64_t n_cand = 0, n_cmp = 0, n_windows = 0, n_ovf = 0, r0 = 0;
+    c->stats.n_batches = 0;
+    c->stats.match_launches = 0;
+    bool again = false;
+    while (r0 < c->nreads) {
+      const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
+      const uint32_t ntiles = nblk(n, TILE);
+      const uint64_t sgrid = std::min(nblk(n, TILE), MAX_GRID);
+      if (!sized) {
+        if ((rc = ensure(c, c->bs[0].tbase, (uint64_t)ntiles + 1))) return rc;
+        if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)ntiles + 1)))) return rc;
+        if ((rc = ensure(c, c->tcount2, (uint64_t)ntiles + 1))) return rc;
+        if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
+        if ((rc = ensure(c, c->stage, std::max<uint64_t>(2ull * n, sgrid * 64)))) return rc;
+        if ((rc = ensure(c, c->spill, sgrid * 64))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
+      }
+      tm.begin(0);
+      switch (c->rw) {
+        case 4: launch_match<4>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr); break;
+        case 8: launch_match<8>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr); break;
+        default: launch_match<12>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr); break;
+      }
+      HIPCHK(c, hipGetLastError());
+      tm.end(0);
+      c->stats.match_launches++;
+      c->stats.n_batches++;
+      if (!sized) {
+        HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters, 16 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint64_t need_stage = c->h_pinned[8 + 7] * sgrid, need_spill = c->h_pinned[8 + 5] * sgrid;
+        if (need_stage > (1ull << 31)) {  // u32 tuple offsets within a batch: retry with half the reads
+          if (n == 1) return fail(c, 6, "one read has %llu tuples (> 2^31)", (unsigned long long)c->h_pinned[8 + 7]);
+          bsz = n / 2;
+          again = true;
+          break;
+        }
+        if (c->h_pinned[3] || need_stage > c->stage.cap || need_spill > c->spill.cap) {
+          // room for every workgroup's tuples / spilled candidates, then the pass starts over
+          // (k_match has already added this batch to the pass-level counters)
+          if (need_stage > c->stage.cap && (rc = ensure(c, c->stage, need_stage + need_stage / 4 + sgrid))) return rc;
+          if (need_spill > c->spill.cap && (rc = ensure(c, c->spill, need_spill + need_spill / 4 + sgrid))) return rc;
+          again = true;
+          break;
+        }
+        n_windows += c->h_pinned[8 + 0];
+        n_cmp += c->h_pinned[8 + 1];
+        n_cand += c->h_pinned[8 + 3];
+        n_ovf += c->h_pinned[8 + 4];
+        if ((rc = ensure(c, c->hits, c->h_pinned[2] + c->h_pinned[8 + 6], true))) return rc;
+      }
+      tm.begin(4);
+      tm.begin(1);
+      rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p, c->stream);
+      if (rc) return rc;
+      tm.end(1);
+      hipLaunchKernelGGL(k_compact, dim3((unsigned)sgrid), dim3(256), 0, c->stream, ntiles, c->bs[0].tbase.p, c->tcount2.p,
+                         c->tpre.p, c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap, c->counters);
+      HIPCHK(c, hipGetLastError());
+      hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->tpre.p, ntiles, c->counters);
+      HIPCHK(c, hipGetLastError());
+      tm.end(4);
+      r0 += n;
+    }
+    if (again) continue;
+    c->last_pp = pp;
+    c->last_max_matches = (uint32_t)max_matches;
+    c->last_exact_blocks = block_mode == 2;
+    if (block_mode == 2) {
+      hipLaunchKernelGGL(k_block_overflow, dim3(1024), dim3(256), 0, c->stream, c->block_table.p, (uint32_t)max_matches,
+                         c->counters);
+      HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(ev1, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 16 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_pinned[3]) {
+      if (!sized) return fail(c, 12, "internal: a capacity guard fired although every batch was sized (flags %llu)",
+                              (unsigned long long)c->h_pinned[3]);
+      c->sized_epoch = 0;  // the pass did not fit after all: run it the careful way
+      return musc_match_device(c, P, nhits);
+    }
+    if (sized) {
+      n_windows = c->h_pinned[8 + 0];
+      n_cmp = c->h_pinned[8 + 1];
+      n_cand = c->h_pinned[8 + 3];
+      n_ovf = c->h_pinned[8 + 4];
+    }
+    c->stats.n_read_windows = n_windows;
+    c->stats.n_candidates = n_cand;
+    c->stats.n_pairs = n_cmp;
+    c->stats.n_descriptors = 0;
+    c->stats.n_overflow_entries = n_ovf;
+    c->stats.n_accepted = c->h_pinned[1];
+    c->stats.n_hits = c->nhits = c->h_pinned[2];
+    c->stats.n_overflow_blocks = check_blocks ? c->h_pinned[5] : ~0ull;
+    if (block_mode == 1 && (c->h_pinned[6] || c->stats.n_batches > planned_batches)) {
+      c->force_exact_blocks = true;  // screening inconclusive: repeat with exact per-block counters
+      rc = musc_match_device(c, P, nhits);
+      c->force_exact_blocks = false;
+      return rc;
+    }
+    c->stats.ms_screen = tm.total(0);
+    c->stats.ms_scan = tm.total(1);
+    c->stats.ms_select = tm.total(4);
+    (void)hipEventElapsedTime(&c->stats.ms_total, ev0, ev1);
+    const uint64_t rec_b = (2 * L + 7) / 8;
+    c->stats.match_bytes = c->nreads * rec_b + n_windows * sizeof(CtxBucket) + n_ovf * sizeof(CtxEntry) + 16 * c->stats.n_hits;
+    c->stats.match_bytes_strict = c->nreads * rec_b + n_windows * 8 + n_cand * sizeof(CtxEntry) + 16 * c->stats.n_hits;
+    if (nhits) *nhits = c->nhits;
+    c->sized_epoch = c->data_epoch;
+    c->sized_params = *P;
+    c->sized_exact_blocks = block_mode == 2;
+    c->sized_bsz = bsz;
+    return 0;
+  }
+}
+
 int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   if (!c) return 1;
   int rc = check_params(c, P);
@@ -754,7 +1106,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   if (!c->db2) return fail(c, 4, "no database loaded");
   if (!c->rd && c->nreads) return fail(c, 4, "no reads loaded");
   HIPCHK(c, hipSetDevice(c->device));
-  rc = musc_db_build_index(c, P->window_width);
+  rc = ensure_index(c, P, c->max_len);
   if (rc) return rc;
 
   const float keep_index_ms = c->stats.ms_index_build;
@@ -817,6 +1169,13 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if ((rc = ensure(c, c->block_table, 1ull << BLOCK_TABLE_BITS))) return rc;
     HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
   }
+  c->stats.index_kind = (uint32_t)c->idx_kind;
+  c->stats.index_bytes = c->idx_kind == 1
+                             ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + (c->idx_novf + 16) * sizeof(CtxEntry)
+                             : ((1ull << c->idx_bits) + 1) * sizeof(Bucket) + (c->idx_novf + 16) * sizeof(uint4);
+  if (c->idx_kind == 1)
+    return match_ctx_pass(c, P, pp, block_mode, block_thr, max_matches, planned_batches, nhits);
+
   Timer tm(c);
   hipEvent_t ev0 = pool_event(c), ev1 = pool_event(c);
   if (!ev0 || !ev1) return fail(c, 10, "hipEventCreate failed");

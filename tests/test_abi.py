@@ -17,7 +17,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.musc_abi_version() == 1
+    assert lib.musc_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -25,7 +25,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.MuscHit) == 16
     # n_windows + 16 windows + ww (+pad) + double + 6 ints + 5 reserved
     assert ctypes.sizeof(_lib.MuscParams) == 4 + 64 + 4 + 8 + 4 * 6 + 4 * 5 + 4
-    assert ctypes.sizeof(_lib.MuscStats) == 8 * 8 + 2 * 4 + 8 * 4 + 8
+    assert ctypes.sizeof(_lib.MuscStats) == 8 * 8 + 2 * 4 + 8 * 4 + 8 + 2 * 4 + 4 * 8
 
 
 def test_init_without_gpu_fails_loudly():

@@ -41,9 +41,18 @@ def _hamming_ok(T_flat, TL, R, h, L, chunk=2_000_000):
     return True
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg5shard"])
-def test_baseline_config_at_full_size(name):
+@pytest.mark.parametrize("name,index", [("cfg3", "auto"), ("cfg3", "classic"), ("cfg5shard", "auto")])
+def test_baseline_config_at_full_size(name, index, monkeypatch):
+    """index "auto": what the library picks -- context buckets + the fused k_match for cfg3 (two
+    windows, 100-bp reads: 120 bases of context), the 64-byte-bucket index + k_screen -> k_confirm
+    for the cfg5 shard (three windows do not fit the context; 10 Gbp would not fit the table);
+    "classic" forces the latter for cfg3 as well."""
     import torch
+    if index == "classic":
+        monkeypatch.setenv("MUSC_INDEX", "classic")
+    else:
+        monkeypatch.delenv("MUSC_INDEX", raising=False)
+    want_kind = 1 if (name, index) == ("cfg3", "auto") else 0
     from muscato_amd import Config, Engine, sorted_hits, synth
     from oracle import literal
     from oracle import muscato_oracle as orc
@@ -68,7 +77,7 @@ def test_baseline_config_at_full_size(name):
     eng = Engine(0)
     try:
         eng.load_targets_device(T.data_ptr(), toff.data_ptr(), NT)
-        eng.build_index(wl.window_width)
+        eng.build_index_for(cfg, L)
         order, ustart = eng.sort_unique_reads_arrays(raw.data_ptr(), roff.data_ptr(), nraw, True)
         U = len(ustart) - 1
         assert eng.n_reads == U and nraw - U < 0.02 * nraw
@@ -91,9 +100,10 @@ def test_baseline_config_at_full_size(name):
         t0 = time.time()
         n_all = eng.match_device(cfg, apply_mmtol=False)
         st = eng.stats()
-        _log("%s: %d reads -> %d candidates, %d pairs, %d accepted tuples; device %.2f ms (first pass, %.1fs wall)"
-             % (name, U, st["n_candidates"], st["n_pairs"], n_all, st["ms_total"], time.time() - t0))
-        assert st["n_reads"] == U and st["n_overflow_blocks"] == 0
+        _log("%s (index kind %d, %.1f GiB): %d reads -> %d candidates, %d pairs, %d accepted tuples; device %.2f ms "
+             "(first pass, %.1fs wall)" % (name, st["index_kind"], st["index_bytes"] / 2**30, U, st["n_candidates"],
+                                            st["n_pairs"], n_all, st["ms_total"], time.time() - t0))
+        assert st["n_reads"] == U and st["n_overflow_blocks"] == 0 and st["index_kind"] == want_kind
         assert st["n_candidates"] >= st["n_pairs"] >= st["n_accepted"] == n_all > 0.5 * U
         h32 = torch.empty((n_all, 4), dtype=torch.int32, device=dev)
         eng.hits_to(h32.data_ptr(), n_all, True)

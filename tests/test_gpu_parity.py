@@ -19,12 +19,25 @@ from cases import make_case, mutate, rand_seq
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["auto", "classic"])
+def eng(request):
+    """Every test of this module runs twice: on the index the library picks by itself (context
+    buckets + the fused k_match wherever the run fits them, see kernels_match.hpp) and with
+    MUSC_INDEX=classic (64-byte buckets, k_screen -> k_confirm)."""
     from muscato_amd import Engine
+    old = os.environ.get("MUSC_INDEX")
+    if request.param == "classic":
+        os.environ["MUSC_INDEX"] = "classic"
+    else:
+        os.environ.pop("MUSC_INDEX", None)
     e = Engine(0)
+    e.index_mode = request.param
     yield e
     e.close()
+    if old is None:
+        os.environ.pop("MUSC_INDEX", None)
+    else:
+        os.environ["MUSC_INDEX"] = old
 
 
 def to_cfg(ocfg):
@@ -330,7 +343,8 @@ def test_low_complexity_stress(eng):
                                      literal.make_params(c, bloom_size=64_000_000, num_hash=6, nthreads=8))
     got = gpu_hits(eng, c, reads, targets, False)
     st = eng.stats()
-    assert st["n_descriptors"] > 1_000_000 and len(got) > 500_000
+    assert st["index_kind"] == (0 if eng.index_mode == "classic" else 1)
+    assert (st["n_descriptors"] if st["index_kind"] == 0 else st["n_pairs"]) > 1_000_000 and len(got) > 500_000
     assert_same(got, exp)
     assert st["n_overflow_blocks"] == 0
     best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
