@@ -138,11 +138,45 @@ __global__ void k_ctx_ovf_set(CtxBucket* __restrict__ T, uint64_t nb, const uint
 struct MatchParams {
   int32_t W, ww, min_dinuc, bits, direct, mmtol, apply_mmtol, max_len, CL;
   uint32_t q1zero_mask;
+  int32_t dbg;  // experiments only (MUSC_DEBUG_MATCH): 1 skip the comparisons, 2 skip the bucket loads, 4 skip phase C
   int32_t win[CTX_MAX_W];
+  // Scalar mask tables, filled by the host (match_tables): a comparison through window k works in
+  // the coordinates of the context stream, where the read sits at bits [sh_k, sh_k + 2 len), sh_k =
+  // 2 * (CL - win[k]).  Word j of
+  //   lm[len][k]  = 0x55555555 & (bits of the read): one bit per base that takes part in cdiff
+  //   wm[k][kk]   = the bits of window kk of the read
+  // need[k] = the windows whose exactness a comparison through window k has to establish: the
+  // ones before k (first-window rule) and k itself when the table is hashed (a direct table's
+  // bucket is the key: the probed window matches by construction).
+  uint32_t need[CTX_MAX_W];
+  uint32_t wm[CTX_MAX_W][CTX_MAX_W][8];
+  uint32_t lm[CTX_BASES + 1][CTX_MAX_W][8];
 };
 
-#define MATCH_LIST 512   // reported candidates of a tile kept in LDS (a cfg3 tile has ~260); more spill to HBM
-#define MATCH_OWN 1024   // overflow items per window whose owner is looked up directly
+// bits [lo, hi) of a 32-bit word as a mask, for any int lo / hi (host and device)
+__host__ __device__ inline uint32_t bit_range_mask(int lo, int hi) {
+  if (hi <= 0 || lo >= 32 || hi <= lo) return 0u;
+  const uint32_t mh = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+  const uint32_t ml = lo <= 0 ? 0xFFFFFFFFu : ~((1u << lo) - 1u);
+  return mh & ml;
+}
+
+// host: the mask tables of a parameter block whose scalar fields are set
+inline void match_tables(MatchParams& mp) {
+  for (int k = 0; k < CTX_MAX_W; k++) {
+    mp.need[k] = 0;
+    if (k >= mp.W) continue;
+    const int sh = 2 * (mp.CL - mp.win[k]);
+    mp.need[k] = ((1u << k) - 1u) | (mp.direct ? 0u : (1u << k));
+    for (int kk = 0; kk < mp.W; kk++)
+      for (int j = 0; j < 8; j++)
+        mp.wm[k][kk][j] = bit_range_mask(sh + 2 * mp.win[kk] - 32 * j, sh + 2 * (mp.win[kk] + mp.ww) - 32 * j);
+    for (int len = 0; len <= CTX_BASES; len++)
+      for (int j = 0; j < 8; j++) mp.lm[len][k][j] = 0x55555555u & bit_range_mask(sh - 32 * j, sh + 2 * len - 32 * j);
+  }
+}
+
+
 #define MATCH_SKETCH_BITS 10
 
 // fit rules of one index entry for a read of rlen bases placed through the window at q1:
@@ -151,64 +185,100 @@ struct MatchParams {
 // (cmd/muscato_screen/main.go:347-353 + cmd/muscato_confirm/main.go:201-203).  *zflag: p == 0 but the
 // pos-0 path would reject -- windows starting at 0 cannot have emitted this placement.
 DEV bool ctx_fit(uint32_t jx, uint32_t rem16, int q1, int ww, int rlen, uint32_t* zflag) {
-  const int left = jx > 65535u ? 65535 : (int)jx, right = (int)rem16;
-  int lim0 = 100 - ww;
+  const int left = (int)(jx > 65535u ? 65535u : jx), right = (int)rem16;
   const int tcap = left + right;  // target length, saturated (exact below 65535)
-  if (lim0 > tcap) lim0 = tcap;
+  const int lim0 = 100 - ww < tcap ? 100 - ww : tcap;
   const bool fit0 = rlen <= lim0;
-  bool ok = q1 <= left;
-  if (left == 0) ok = ok && fit0;
-  else ok = ok && (rlen - q1 <= right);
-  *zflag = (left == q1 && !fit0) ? 1u : 0u;
-  return ok;
+  const bool inside = left == 0 ? fit0 : (rlen - q1 <= right);  // no short-circuit: plain selects, no branches
+  *zflag = (uint32_t)(left == q1) & (uint32_t)!fit0;
+  return (q1 <= left) & inside;
 }
 
-// cdiff of a whole read against the context stream c (240 bits in c[0..7], the high half of c[7]
-// is not part of it) read from bit `sh` on (wave-uniform: 2 * (CL - q1)); returns the pair's result
-// word (NX_REJECT, or nmiss | NX_DUP | NX_ACC0 | window << 20 | read slot << 24).
-//   exact0: windows that take part for this read (minus the ones the pos-0 rule excludes)
-template <int RW, bool W2>
-DEV uint32_t ctx_compare(const uint32_t* __restrict__ r, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                         uint32_t c4, uint32_t c5, uint32_t c6, uint32_t c7, uint32_t sh, uint32_t k,
-                         const MatchParams* __restrict__ mp, int W, int ww, int win0, int win1, uint32_t exact0,
-                         uint32_t budget, uint32_t slot) {
-  const uint32_t c[10] = {c0, c1, c2, c3, c4, c5, c6, c7 & 0xFFFFu, 0u, 0u};
-  uint32_t t[RW - 1];
+// The meta word of a read in LDS (phase A of k_match): length | budget << 17 | windows that take
+// part << 24.
+#define REC_LEN(w) ((w) & 0xFFFFu)
+#define REC_BUDGET(w) (((w) >> 17) & 0x7Fu)
+#define REC_VALID(w) ((w) >> 24)
+
+// utils/entropy.go:5-40 for a window of at most 16 bases without X: the window is one 32-bit
+// word, a dinucleotide one 4-bit field of it (rec_count_dinuc is the general form)
+template <class R>
+DEV int rec_count_dinuc16(const R& r, uint32_t q1, int ww) {
+  const uint32_t key = (uint32_t)r.ext(2 * q1);
+  uint32_t seen = 0;
+#pragma unroll
+  for (int i = 0; i < 15; i++)
+    if (i + 1 < ww) seen |= 1u << ((key >> (2 * i)) & 15u);
+  return __popc(seen);
+}
+
+// The read's IMAGE for window k: its bases moved to where the context stream holds the target
+// bases it is compared with -- the read shifted left by sh = 2 * (CL - q1) bits, eight words
+// (240 bits).  Phase A of k_match builds it once per (read, window); every comparison of the read
+// through that window is then a plain word-by-word XOR against a bucket's context, with no
+// per-entry alignment.  sh is wave-uniform.
+template <int RW>
+DEV void read_image(const Rec<RW>& rec, uint32_t sh, uint32_t (&img)[8]) {
   const uint32_t bs = sh & 31u;
-  switch (__builtin_amdgcn_readfirstlane((int)(sh >> 5))) {
-#define MUSC_CTX_CASE(WO)                                                                      \
-  case WO:                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < RW - 1; j++) {                                       \
-      const uint32_t lo = (j + WO < 8) ? c[j + WO < 8 ? j + WO : 8] : 0u;                       \
-      const uint32_t hi = (j + WO + 1 < 8) ? c[j + WO + 1 < 8 ? j + WO + 1 : 8] : 0u;           \
-      t[j] = __funnelshift_r(lo, hi, bs);                                                      \
-    }                                                                                          \
+  // word j of (bases << sh) = bases[j - wo] << bs | bases[j - wo - 1] >> (32 - bs), wo = sh / 32: the
+  // word offset is resolved by a scalar branch, each case names its registers statically (the
+  // record's last word is the length, not bases)
+#define MUSC_IMG_W(Q) (((Q) >= 0 && (Q) < RW - 1) ? rec.w[((Q) >= 0 && (Q) < RW - 1) ? (Q) : 0] : 0u)
+#define MUSC_IMG_CASE(WO)                                                  \
+  case WO:                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 8; j++) {                        \
+      const uint32_t hi = MUSC_IMG_W(j - WO), lo = MUSC_IMG_W(j - WO - 1); \
+      img[j] = bs ? ((hi << bs) | (lo >> (32u - bs))) : hi;                \
+    }                                                                      \
     break;
-    MUSC_CTX_CASE(0) MUSC_CTX_CASE(1) MUSC_CTX_CASE(2) MUSC_CTX_CASE(3)
-    MUSC_CTX_CASE(4) MUSC_CTX_CASE(5) MUSC_CTX_CASE(6) MUSC_CTX_CASE(7)
-#undef MUSC_CTX_CASE
+  switch (__builtin_amdgcn_readfirstlane((int)(sh >> 5))) {
+    MUSC_IMG_CASE(0) MUSC_IMG_CASE(1) MUSC_IMG_CASE(2) MUSC_IMG_CASE(3)
+    MUSC_IMG_CASE(4) MUSC_IMG_CASE(5) MUSC_IMG_CASE(6) MUSC_IMG_CASE(7)
     default:
 #pragma unroll
-      for (int j = 0; j < RW - 1; j++) t[j] = 0u;
+      for (int j = 0; j < 8; j++) img[j] = 0u;
       break;
   }
-  const uint32_t len = r[RW - 1] & 0xFFFFu;
-  const int len2 = 2 * (int)len;
-  uint32_t nx = 0, exact = exact0;
+#undef MUSC_IMG_CASE
+#undef MUSC_IMG_W
+}
+
+// cdiff of a whole read against one context (cmd/muscato_confirm/main.go:151-159, 205-211): the
+// read's image words x the context words c (c[7] cut to its low half), and from the same mismatch
+// mask which windows of the read match the target exactly here.  Returns the pair's result word
+// (NX_REJECT, or nmiss | NX_DUP | NX_ACC0 | window << 20 | read slot << 24).
+//   k      = the probed window (wave-uniform), sh = 2 * (CL - win[k])
+//   exact0 = windows that take part for this read (minus the ones the pos-0 rule excludes)
+//   ULEN   : every read of the wave-tile has the same length `len` (wave-uniform) -- the masks are
+//            rows of the host's tables then, read by the scalar unit; otherwise the length mask is
+//            per lane arithmetic
+template <bool ULEN>
+DEV uint32_t ctx_score(const uint32_t (&img)[8], const uint32_t (&c)[8], uint32_t sh, uint32_t k,
+                       const MatchParams* __restrict__ mp, int W, uint32_t exact0, uint32_t budget, uint32_t slot,
+                       uint32_t len) {
+  uint32_t d[8];
+  uint32_t nx = 0;
+  // (readfirstlane: tells the compiler the index is wave-uniform, so the row is read by scalar loads)
+  const uint32_t* __restrict__ lmrow = mp->lm[ULEN ? __builtin_amdgcn_readfirstlane((int)len) : 0][__builtin_amdgcn_readfirstlane((int)k)];
+  const uint32_t ku = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
 #pragma unroll
-  for (int j = 0; j < RW - 1; j++) {
-    const uint32_t x = r[j] ^ t[j];
-    uint32_t d = (x | (x >> 1)) & 0x55555555u;
-    const int rem = len2 - 32 * j;
-    d &= rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-    nx += __popc(d);
-    if constexpr (W2) {
-      if (d & window_word_mask(win0, ww, j)) exact &= ~1u;
-      if (W > 1 && (d & window_word_mask(win1, ww, j))) exact &= ~2u;
-    } else {
-      for (int kk = 0; kk < W; kk++)
-        if (d & window_word_mask(mp->win[kk], ww, j)) exact &= ~(1u << kk);
-    }
+  for (int j = 0; j < 8; j++) {
+    const uint32_t x = img[j] ^ c[j];
+    uint32_t m;
+    if constexpr (ULEN) m = lmrow[j];
+    else m = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
+    d[j] = (x | (x >> 1)) & m;
+    nx += __popc(d[j]);
+  }
+  uint32_t exact = exact0;
+  const uint32_t need = mp->need[ku];
+  for (int kk = 0; kk < W; kk++) {
+    if (!((need >> kk) & 1u)) continue;  // wave-uniform
+    uint32_t acc = 0;
+    const uint32_t* __restrict__ wmrow = mp->wm[ku][kk];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc |= d[j] & wmrow[j];
+    if (acc) exact &= ~(1u << kk);
   }
   // the reference's confirm for window k accepts the pair (it counts towards that window-key
   // block's MaxMatches); the tuple is reported here only if k is the first window that accepts it
@@ -217,34 +287,75 @@ DEV uint32_t ctx_compare(const uint32_t* __restrict__ r, uint32_t c0, uint32_t c
   return (first ? nx : (nx | NX_DUP)) | NX_ACC0 | (k << 20) | (slot << 24);
 }
 
-// k_match -- muscato_screen + the join + muscato_confirm + the per-read best/MMTol filter for one
-// tile of 256 reads per workgroup iteration (persistent workgroups).
-//   phase A  a thread per read: record -> registers and LDS; per window the length gate +
+// Everything a wave shares through LDS is its own: a wave's LDS operations execute in order, so
+// all that is needed between a write and another lane's read is that the compiler keeps the order.
+DEV void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// A wave-uniform value the compiler must treat as new: what is derived from it (the scalar masks
+// of a comparison) is recomputed by the scalar unit where it is used -- that unit idles otherwise
+// -- instead of being kept in (and spilled from) scalar registers across the whole kernel.
+DEV uint32_t opaque_s(uint32_t x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+
+// inclusive scan over the 64 lanes of a wave with DPP moves only (no LDS round trips): rows of 16
+// by row_shr 1/2/4/8, then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3
+DEV uint32_t wave_scan_incl(uint32_t v) {
+#define MUSC_DPP_ADD(CTRL, ROWS) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false)
+  MUSC_DPP_ADD(0x111, 0xF);  // row_shr:1
+  MUSC_DPP_ADD(0x112, 0xF);  // row_shr:2
+  MUSC_DPP_ADD(0x114, 0xF);  // row_shr:4
+  MUSC_DPP_ADD(0x118, 0xF);  // row_shr:8
+  MUSC_DPP_ADD(0x142, 0xA);  // row_bcast:15
+  MUSC_DPP_ADD(0x143, 0xC);  // row_bcast:31
+#undef MUSC_DPP_ADD
+  return v;
+}
+
+#define WT 64            // reads per wave-tile
+#define MATCH_WLIST 128  // reported candidates of a wave-tile kept in LDS (cfg3: ~65); more spill to HBM
+#define MATCH_WOWN 64    // overflow items handled per chunk of phase C (a lane per item)
+
+// k_match -- muscato_screen + the join + muscato_confirm + the per-read best/MMTol filter.
+// A WAVE works alone on a wave-tile of 64 consecutive reads (persistent waves, no workgroup
+// barrier inside the loop: the waves of a CU drift apart, so one wave's memory round trips hide
+// behind the others' arithmetic).
+//   phase A  a lane per read: record -> registers; per window the length gate +
 //            CountDinuc >= MinDinuc (cmd/muscato_window_reads/main.go:106-118 ==
-//            cmd/muscato_screen/main.go:174-185) and the bucket of the window key
-//   phase B  per window, four rounds per wave: a QUAD of lanes fetches one 128-byte bucket (32
+//            cmd/muscato_screen/main.go:174-185), the bucket of the window key, and the read's
+//            image for that window (read_image) -> LDS
+//   phase B  per window four rounds of 16 probes: a QUAD of lanes fetches one 128-byte bucket (32
 //            bytes per lane, two dwordx4, non-temporal: every line is requested once); lane 0 holds
 //            count/ovf/gene/jx, lanes 1..3 hold one entry's context each and run cdiff on it where
-//            it arrived (ctx_compare) against the read's record from LDS.  All rounds of a window
-//            share the shift 2*(CL - q1), so it is wave-uniform.
-//   phase C  per window: the entries beyond a bucket's third (CtxEntry in E) as one flat list over
-//            the workgroup, like k_screen's phase C
+//            it arrived: context words XOR the read's image from LDS (ctx_score).  All probes of a
+//            round belong to one window, so every mask is a scalar.  The W x 4 rounds run through
+//            a ring of four register buffers: a round's registers are refilled with the same round
+//            of the next window as soon as it has been used.
+//   phase C  the entries beyond a bucket's third (CtxEntry in E) of all the wave-tile's probes as
+//            one flat list, a lane per entry
 //   phase D  best[read] = min nmiss over its reported pairs (LDS atomicMin, filled during B/C),
 //            tuples with nmiss <= best + MMTol per read (cmd/muscato_combine_windows/main.go:36-60;
-//            all of them when apply_mmtol == 0), a scan over the tile's reads, and the tuples
-//            themselves, read-major, into the workgroup's region of `stage`; k_compact closes the
-//            gaps between tiles afterwards.
-// Reported candidates wait in an LDS list (code, gene, pos); a tile with more than MATCH_LIST of
-// them spills the rest to the workgroup's slice of `spill`.
+//            all of them when apply_mmtol == 0), a wave scan over the 64 reads, and the tuples
+//            themselves, read-major, into the wave's region of `stage`; k_compact_w closes the
+//            gaps between wave-tiles afterwards.
+// Reported candidates wait in an LDS list (code, gene, pos); a wave-tile with more than
+// MATCH_WLIST of them spills the rest to the wave's slice of `spill`.
 // MaxMatches accounting as in k_confirm: block_mode 1 = count-min sketch per workgroup in LDS,
 // 2 = exact global counters.
 // counters (batch-local block = counters + 8): [0] valid windows, [1] entries compared (passed the
-// fit rules), [3] index entries walked, [4] overflow entries walked, [5] largest spill any
-// workgroup needed, [6] tuples staged, [7] largest number of tuples any workgroup staged;
-// pass-level [1] reported pairs, [3] flags (1: stage region ran out, 4: spill region ran out),
-// [6] a sketch cell reached block_thr.
+// fit rules), [3] index entries walked, [4] overflow entries walked, [5] largest spill any wave
+// needed, [6] tuples staged, [7] largest number of tuples any wave staged; pass-level [1]
+// reported pairs, [3] flags (1: a stage region ran out, 4: a spill region ran out), [6] a sketch
+// cell reached block_thr.
+#ifndef MATCH_RING
+#define MATCH_RING 4  // rounds (of 16 bucket lines) a wave keeps in flight: 1, 2 or 4
+#endif
+#ifndef MATCH_WAVES
+#define MATCH_WAVES 4  // waves per SIMD the register allocator leaves room for (128 VGPRs)
+#endif
 template <int RW, bool W2>
-__global__ __launch_bounds__(TILE, 5) void k_match(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
+__global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                    const MatchParams* __restrict__ mp,
                                                    const uint16_t* __restrict__ nmiss_tab,
                                                    const CtxBucket* __restrict__ T, const CtxEntry* __restrict__ E,
@@ -254,319 +365,331 @@ __global__ __launch_bounds__(TILE, 5) void k_match(const uint32_t* __restrict__ 
                                                    int block_mode, uint32_t block_thr,
                                                    uint32_t* __restrict__ block_table,
                                                    unsigned long long* __restrict__ counters) {
-  extern __shared__ uint32_t s_dyn[];  // block_mode != 0: TILE * W per-(read, window) counters, then (mode 1) the sketch
-  __shared__ uint32_t s_rec[TILE * RW];
-  __shared__ uint32_t s_bb[CTX_MAX_W * TILE];  // bucket of (window, read), WB_NONE when the window takes no part
-  __shared__ uint32_t s_valid[TILE], s_best[TILE];
-  __shared__ uint32_t s_lcode[MATCH_LIST], s_lgene[MATCH_LIST], s_lpos[MATCH_LIST];
-  __shared__ uint32_t s_oc[TILE], s_ovf[TILE], s_pref[TILE + 1];  // phase C; s_oc / s_ovf double as cnt / base in phase D
-  __shared__ uint16_t s_own[MATCH_OWN];
-  __shared__ uint32_t s_wsum[TILE / 64];
-  __shared__ uint32_t s_nlist;
+  constexpr int WMAX = W2 ? 2 : CTX_MAX_W;
+  constexpr int NWAVE = TILE / 64;
+  extern __shared__ uint32_t s_dyn[];  // block_mode != 0: NWAVE x W x 64 per-(window, read) counters, then (mode 1) the sketch
+  __shared__ uint32_t s_img[NWAVE][WMAX * WT * 8];  // the read's image per (window, read)
+  __shared__ uint32_t s_meta[NWAVE][WT];            // length | budget << 17 | valid windows << 24
+  __shared__ uint32_t s_bb[NWAVE][WMAX * WT];       // bucket of (window, read), WB_NONE when the window takes no part
+  __shared__ uint32_t s_oc[NWAVE][WMAX * WT];       // phase B/C: overflow entries of the probe; phase D: cnt[64], base[64]
+  __shared__ uint32_t s_ovf[NWAVE][WMAX * WT];      // where in E
+  __shared__ uint32_t s_best[NWAVE][WT];
+  __shared__ uint32_t s_lcode[NWAVE][MATCH_WLIST], s_lgene[NWAVE][MATCH_WLIST], s_lpos[NWAVE][MATCH_WLIST];
+  __shared__ uint32_t s_oix[NWAVE][MATCH_WOWN];  // phase C: flat item -> index within its bucket's overflow list
+  __shared__ uint8_t s_own[NWAVE][MATCH_WOWN];   //          flat item -> probe (window * 64 + read)
   __shared__ uint16_t s_nm[CONF_NM];
-  uint32_t* const s_cnt = s_oc;
-  uint32_t* const s_base = s_ovf;
 
   const int W = mp->W, ww = mp->ww, CL = mp->CL;
   const int win0 = mp->win[0], win1 = mp->win[1];
   const uint32_t q1zero = mp->q1zero_mask;
-  uint32_t* const s_wcnt = s_dyn;
-  uint32_t* const s_sketch = s_dyn + TILE * W;
+  const int dbg = mp->dbg;
+  uint32_t* const s_sketch = s_dyn + NWAVE * WT * W;
   for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)mp->max_len ? nmiss_tab[t] : (uint16_t)0;
   if (block_mode == 1)
     for (uint32_t t = threadIdx.x; t < (1u << MATCH_SKETCH_BITS); t += TILE) s_sketch[t] = 0;
-  lds_barrier();
+  if (blockIdx.x == 0 && threadIdx.x == 0) tcount2[(n + WT - 1) / WT] = 0;
+  __syncthreads();
 
-  const uint32_t ntiles = (n + TILE - 1) / TILE;
-  const uint64_t region = stage_cap / gridDim.x, region0 = region * blockIdx.x;
-  const uint64_t sregion = spill_cap / gridDim.x, sregion0 = sregion * blockIdx.x;
-  uint64_t used = 0;      // tuples this workgroup has staged so far (uniform across the workgroup)
-  uint32_t maxspill = 0;  // largest spill a tile of this workgroup needed
-  unsigned long long nvalid = 0, ncand = 0, ncmp = 0, novf = 0, nrep = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) tcount2[ntiles] = 0;
+  const uint32_t nwt = (n + WT - 1) / WT;
+  const uint32_t gw = blockIdx.x * NWAVE + (threadIdx.x >> 6), nw = gridDim.x * NWAVE;
+  const uint64_t region = stage_cap / nw, region0 = region * gw;
+  const uint64_t sregion = spill_cap / nw, sregion0 = sregion * gw;
+  uint64_t used = 0;      // tuples this wave has staged so far (wave-uniform)
+  uint32_t maxspill = 0;  // largest spill a wave-tile of this wave needed
+  uint32_t nvalid = 0, ncand = 0, ncmp = 0, novf = 0, nrep = 0;  // per lane: far below 2^32
+  const uint32_t mmtol = (uint32_t)mp->mmtol;
+  const bool apply = mp->apply_mmtol != 0;
 
-  auto wg_scan = [&](uint32_t v, uint32_t* total) -> uint32_t {
+  for (uint32_t wt = gw; wt < nwt; wt += nw) {
+    // (the lane's LDS addresses are derived afresh in every iteration: kept across the loop they
+    // would occupy dozens of registers and spill)
     const uint32_t tid = opaque(threadIdx.x);
-    const int lane = tid & 63, wid = tid >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d);
-      if (lane >= d) inc += o;
-    }
-    lds_barrier();  // earlier readers of s_wsum are done
-    if (lane == 63) s_wsum[wid] = inc;
-    lds_barrier();
-    uint32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < TILE / 64; w++) {
-      if (w < wid) woff += s_wsum[w];
-      tot += s_wsum[w];
-    }
-    *total = tot;
-    return woff + inc - v;
-  };
-
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t lane = tid & 63, wid = tid >> 6, part = lane & 3;
+    uint32_t* const img_l = s_img[wid];
+    uint32_t* const bb_l = s_bb[wid];
+    uint32_t* const oc_l = s_oc[wid];
+    uint32_t* const ovf_l = s_ovf[wid];
+    uint32_t* const cnt_l = s_oc[wid];
+    uint32_t* const base_l = s_oc[wid] + WT;
+    uint32_t* const wcnt_l = s_dyn + wid * WT * W;
     // ---- phase A
+    uint32_t ulen;  // the common read length of the wave-tile, or ~0 (wave-uniform)
     {
-      const uint32_t tida = opaque(threadIdx.x);
-      const uint32_t i = tile * TILE + tida;
+      const uint32_t i = wt * WT + lane;
       const bool active = i < n;
       Rec<RW> rec;
       rec.load(rd + (r0 + (active ? i : 0)) * (uint64_t)RW, RW);
-#pragma unroll
-      for (int q = 0; q < RW / 4; q++)
-        *reinterpret_cast<uint4*>(&s_rec[tida * RW + 4 * q]) =
-            make_uint4(rec.w[4 * q], rec.w[4 * q + 1], rec.w[4 * q + 2], rec.w[4 * q + 3]);
       const int len = (int)rec.len();
       uint32_t valid = 0;
       for (int k = 0; k < W; k++) {
         uint32_t b = WB_NONE;
+        const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
         if (active) {
-          const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
           bool pt = (uint32_t)len >= q2;
-          if (pt && mp->min_dinuc > 0) pt = rec_count_dinuc(rec, rec, false, q1, ww) >= mp->min_dinuc;
+          if (pt && mp->min_dinuc > 0)
+            pt = (ww <= 16 ? rec_count_dinuc16(rec, q1, ww) : rec_count_dinuc(rec, rec, false, q1, ww)) >= mp->min_dinuc;
           if (pt) {
             b = rec_bucket(rec, rec, false, q1, ww, mp->bits, mp->direct);
             valid |= 1u << k;
           }
         }
-        s_bb[k * TILE + tida] = b;
+        bb_l[k * WT + lane] = b;
+        uint32_t img[8];
+        read_image<RW>(rec, 2u * (uint32_t)(CL - (int)q1), img);
+        uint4* dst = reinterpret_cast<uint4*>(&img_l[(k * WT + lane) * 8]);
+        dst[0] = make_uint4(img[0], img[1], img[2], img[3]);
+        dst[1] = make_uint4(img[4], img[5], img[6], img[7]);
       }
-      s_valid[tida] = valid;
-      s_best[tida] = 0xFFFFFFFFu;
+      const uint32_t budget = len < CONF_NM ? s_nm[len] : 0u;  // (reads on this path are at most 120 bases)
+      s_meta[wid][lane] = (uint32_t)len | ((budget > 127u ? 127u : budget) << 17) | (valid << 24);
+      s_best[wid][lane] = 0xFFFFFFFFu;
       nvalid += __popc(valid);
-      if (tida == 0) s_nlist = 0;
       if (block_mode)
-        for (uint32_t t = tida; t < TILE * (uint32_t)W; t += TILE) s_wcnt[t] = 0;
+        for (uint32_t t = lane; t < WT * (uint32_t)W; t += 64) wcnt_l[t] = 0;
+      // every read of the wave-tile of one length: the comparisons use scalar length masks
+      const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
+      ulen = __ballot(active && (uint32_t)len != len0) == 0 ? len0 : 0xFFFFFFFFu;
     }
-    lds_barrier();
+    wave_lds_sync();
+    uint32_t nlist = 0;  // reported candidates of this wave-tile so far (wave-uniform)
 
-    // one reported candidate per set lane of the vote: a wave claims its list slots with one LDS
-    // atomic and fills them in lane order
+    // one reported candidate per set lane of the vote, appended in lane order
     auto report = [&](uint32_t w, uint32_t gene, uint32_t pos) {
       const bool acc = w != NX_REJECT;
-      if (acc && block_mode) atomicAdd(&s_wcnt[(w >> 24) * W + ((w >> 20) & 15u)], 1u);
+      if (acc && block_mode) atomicAdd(&wcnt_l[((w >> 20) & 15u) * WT + (w >> 24)], 1u);
       const bool rep = acc && !(w & NX_DUP);
       const unsigned long long vote = __ballot(rep);
       if (vote == 0) return;
-      if (rep) atomicMin(&s_best[w >> 24], w & 0xFFFFu);
-      uint32_t first = 0;
       const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
-      if (below == 0 && rep) first = atomicAdd(&s_nlist, (uint32_t)__popcll(vote));
-      first = __builtin_amdgcn_readlane(first, __builtin_ctzll(vote));
+      const uint32_t slot = nlist + below;
+      nlist += (uint32_t)__popcll(vote);
       if (!rep) return;
+      atomicMin(&s_best[wid][w >> 24], w & 0xFFFFu);
       nrep++;
-      const uint32_t slot = first + below;
-      if (slot < MATCH_LIST) {
-        s_lcode[slot] = w;
-        s_lgene[slot] = gene;
-        s_lpos[slot] = pos;
-      } else if (slot - MATCH_LIST < sregion) {
-        spill[sregion0 + (slot - MATCH_LIST)] = make_uint4(w, gene, pos, 0u);
+      if (slot < MATCH_WLIST) {
+        s_lcode[wid][slot] = w;
+        s_lgene[wid][slot] = gene;
+        s_lpos[wid][slot] = pos;
+      } else if (slot - MATCH_WLIST < sregion) {
+        spill[sregion0 + (slot - MATCH_WLIST)] = make_uint4(w, gene, pos, 0u);
       }
     };
 
-    for (int k = 0; k < W; k++) {
-      const int q1 = mp->win[k];
-      const uint32_t sh = 2u * (uint32_t)(CL - q1);
-      // ---- phase B: four rounds, all loads issued before the first is used
-      {
-        const uint32_t tidb = opaque(threadIdx.x);
-        const uint32_t lane = tidb & 63, wid = tidb >> 6, part = lane & 3;
-        uint4 va[4], vb[4];
+    // one entry (context words c, c[7] still carrying rem16 in its high half) of probe (k, ri)
+    auto compare = [&](auto ulen_tag, uint32_t k, int q1, uint32_t sh, uint32_t ri, uint32_t jx, bool live,
+                       uint32_t (&c)[8]) -> uint32_t {
+      constexpr bool ULEN = decltype(ulen_tag)::value;
+      const uint32_t meta = s_meta[wid][ri];
+      const int rlen = (int)REC_LEN(meta);
+      uint32_t z = 0;
+      const bool ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, rlen, &z);
+      uint32_t w = NX_REJECT;
+      if (ok) {
+        ncmp++;
+        uint32_t img[8];
+        const uint4* src = reinterpret_cast<const uint4*>(&img_l[(k * WT + ri) * 8]);
+        const uint4 i0 = src[0], i1 = src[1];
+        img[0] = i0.x; img[1] = i0.y; img[2] = i0.z; img[3] = i0.w; img[4] = i1.x; img[5] = i1.y; img[6] = i1.z; img[7] = i1.w;
+        c[7] &= 0xFFFFu;
+        const uint32_t exact0 = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
+        w = ctx_score<ULEN>(img, c, sh, k, mp, W, exact0, REC_BUDGET(meta), ri, ULEN ? ulen : (uint32_t)rlen);
+      }
+      return w;
+    };
+
+    // ---- phase B
+    auto issue = [&](int k, int rr, uint4& a, uint4& b2) {
+      const uint32_t b = bb_l[k * WT + rr * 16 + (lane >> 2)];
+      a = make_uint4(0, 0, 0, 0);
+      b2 = make_uint4(0, 0, 0, 0);
+      if (b != WB_NONE && !(dbg & 2)) {
+        const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b) + 2 * part;
+        const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
+        a = make_uint4(x.x, x.y, x.z, x.w);
+        b2 = make_uint4(y.x, y.y, y.z, y.w);
+      }
+    };
+    auto process = [&](auto ulen_tag, int k, int q1, uint32_t sh, int rr, const uint4& a, const uint4& b2) {
+      // (opaque: the probes of round rr belong to the same reads for every window; the compiler
+      // would otherwise keep what it derives from them in registers across the window loop)
+      const uint32_t ri = opaque((uint32_t)rr * 16 + (lane >> 2));
+      // block 0 sits in the quad's first lane (quad_perm [0,0,0,0]); every lane executes the moves
+#define MUSC_Q0(X) (uint32_t)__builtin_amdgcn_mov_dpp((int)(X), 0x00, 0xF, 0xF, true)
+      const uint32_t cnt = MUSC_Q0(a.x);
+      const uint32_t g0 = MUSC_Q0(a.z), g1 = MUSC_Q0(a.w), g2 = MUSC_Q0(b2.x);
+      const uint32_t j0 = MUSC_Q0(b2.y), j1 = MUSC_Q0(b2.z), j2 = MUSC_Q0(b2.w);
+#undef MUSC_Q0
+      if (part == 0) {
+        ncand += cnt;
+        oc_l[k * WT + ri] = cnt > CTX_INLINE ? cnt - CTX_INLINE : 0u;
+        ovf_l[k * WT + ri] = a.y;
+      }
+      const uint32_t gene = part == 1 ? g0 : (part == 2 ? g1 : g2);
+      const uint32_t jx = part == 1 ? j0 : (part == 2 ? j1 : j2);
+      uint32_t c[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+      const bool live = part >= 1 && part - 1 < cnt && !(dbg & 1);
+      const uint32_t w = compare(ulen_tag, (uint32_t)k, q1, sh, ri, jx, live, c);
+      report(w, gene, jx - (uint32_t)q1);
+    };
+    {
+      // a ring of four register buffers over the W x 4 rounds: a round's registers are refilled
+      // with the same round of the next window as soon as it has been used
+      uint4 va[MATCH_RING], vb[MATCH_RING];
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const uint32_t ri = wid * 64 + rr * 16 + (lane >> 2);
-          const uint32_t b = s_bb[k * TILE + ri];
-          va[rr] = make_uint4(0, 0, 0, 0);
-          vb[rr] = make_uint4(0, 0, 0, 0);
-          if (b != WB_NONE) {
-            const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b) + 2 * part;
-            const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
-            va[rr] = make_uint4(x.x, x.y, x.z, x.w);
-            vb[rr] = make_uint4(y.x, y.y, y.z, y.w);
+      for (int rr = 0; rr < MATCH_RING; rr++) issue(0, rr, va[rr], vb[rr]);
+      auto rounds = [&](auto ulen_tag) {
+#pragma unroll 1
+        for (int k = 0; k < W; k++) {
+          // the window's geometry, new to the compiler in every iteration (opaque_s): the scalar
+          // masks derived from it live for these four rounds only
+          const int q1 = W2 ? (k == 0 ? win0 : win1) : mp->win[k];
+          const uint32_t sh = opaque_s(2u * (uint32_t)(CL - q1));
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            process(ulen_tag, k, q1, sh, rr, va[rr % MATCH_RING], vb[rr % MATCH_RING]);
+            // refill the slot with the round MATCH_RING ahead (this window's, or the next one's)
+            if (rr + MATCH_RING < 4) issue(k, rr + MATCH_RING, va[rr % MATCH_RING], vb[rr % MATCH_RING]);
+            else if (k + 1 < W) issue(k + 1, rr + MATCH_RING - 4, va[rr % MATCH_RING], vb[rr % MATCH_RING]);
           }
         }
+      };
+      if (ulen != 0xFFFFFFFFu) rounds(std::true_type{}); else rounds(std::false_type{});
+    }
+    wave_lds_sync();
+
+    // ---- phase C: the overflow entries of the wave-tile's W x 64 probes, MATCH_WOWN per chunk
+    if (!(dbg & 4)) {
+      uint32_t oc[WMAX], pre[WMAX];
+      uint32_t total = 0;
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const uint32_t ri = wid * 64 + rr * 16 + (lane >> 2);
-          // block 0 sits in the quad's first lane (quad_perm [0,0,0,0]); every lane executes the moves
-#define MUSC_Q0(X) (uint32_t)__builtin_amdgcn_mov_dpp((int)(X), 0x00, 0xF, 0xF, true)
-          const uint32_t cnt = MUSC_Q0(va[rr].x);
-          const uint32_t g0 = MUSC_Q0(va[rr].z), g1 = MUSC_Q0(va[rr].w), g2 = MUSC_Q0(vb[rr].x);
-          const uint32_t j0 = MUSC_Q0(vb[rr].y), j1 = MUSC_Q0(vb[rr].z), j2 = MUSC_Q0(vb[rr].w);
-#undef MUSC_Q0
-          if (part == 0) {
-            ncand += cnt;
-            s_oc[ri] = cnt > CTX_INLINE ? cnt - CTX_INLINE : 0u;
-            s_ovf[ri] = va[rr].y;
-          }
-          const uint32_t gene = part == 1 ? g0 : (part == 2 ? g1 : g2);
-          const uint32_t jx = part == 1 ? j0 : (part == 2 ? j1 : j2);
-          const uint32_t* __restrict__ r = &s_rec[ri * RW];
-          uint32_t rr_w[RW];
+      for (int k = 0; k < WMAX; k++) {
+        oc[k] = pre[k] = 0;
+        if (k >= W) continue;
+        oc[k] = oc_l[k * WT + lane];
+        const uint32_t inc = wave_scan_incl(oc[k]);
+        pre[k] = total + inc - oc[k];
+        total += __builtin_amdgcn_readlane(inc, 63);
+        novf += oc[k];
+      }
+      for (uint32_t c0 = 0; c0 < total; c0 += MATCH_WOWN) {
 #pragma unroll
-          for (int q = 0; q < RW / 4; q++) {
-            const uint4 a = *reinterpret_cast<const uint4*>(r + 4 * q);
-            rr_w[4 * q] = a.x; rr_w[4 * q + 1] = a.y; rr_w[4 * q + 2] = a.z; rr_w[4 * q + 3] = a.w;
+        for (int k = 0; k < WMAX; k++) {
+          if (k >= W) continue;
+          // this lane's items of window k that fall into [c0, c0 + MATCH_WOWN)
+          const uint32_t e_lo = c0 > pre[k] ? c0 - pre[k] : 0u;
+          const uint32_t e_hi = pre[k] + oc[k] > c0 + MATCH_WOWN ? (c0 + MATCH_WOWN > pre[k] ? c0 + MATCH_WOWN - pre[k] : 0u) : oc[k];
+          for (uint32_t e = e_lo; e < e_hi; e++) {
+            s_own[wid][pre[k] + e - c0] = (uint8_t)(k * WT + lane);
+            s_oix[wid][pre[k] + e - c0] = e;
           }
-          const int rlen = (int)(rr_w[RW - 1] & 0xFFFFu);
-          uint32_t z = 0;
-          bool ok = part >= 1 && part - 1 < cnt;
-          if (ok) ok = ctx_fit(jx, vb[rr].w >> 16, q1, ww, rlen, &z);
-          uint32_t w = NX_REJECT;
-          if (ok) {
-            ncmp++;
-            uint32_t exact0 = s_valid[ri];
-            if (z) exact0 &= ~q1zero;
-            const uint32_t budget = rlen < CONF_NM ? s_nm[rlen] : nmiss_tab[rlen];
-            w = ctx_compare<RW, W2>(rr_w, va[rr].x, va[rr].y, va[rr].z, va[rr].w, vb[rr].x, vb[rr].y, vb[rr].z,
-                                    vb[rr].w, sh, (uint32_t)k, mp, W, ww, win0, win1, exact0, budget, ri);
+        }
+        wave_lds_sync();
+        {
+          const uint32_t t = c0 + lane;
+          const bool have = t < total && !(dbg & 1);
+          uint32_t k = 0, seg = 0, gene = 0, jx = 0, w = NX_REJECT;
+          uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (have) {
+            const uint32_t probe = s_own[wid][t - c0];
+            const uint32_t e = s_oix[wid][t - c0];
+            k = probe >> 6;
+            seg = probe & 63u;
+            const uint32_t* __restrict__ pe =
+                reinterpret_cast<const uint32_t*>(E + ((uint64_t)ovf_l[probe] + e));
+            const uint2 hd = *reinterpret_cast<const uint2*>(pe);
+            const u32x4_u x = *reinterpret_cast<const u32x4_u*>(pe + 2);
+            const u32x4_u y = *reinterpret_cast<const u32x4_u*>(pe + 6);
+            gene = hd.x;
+            jx = hd.y;
+            c[0] = x.x; c[1] = x.y; c[2] = x.z; c[3] = x.w; c[4] = y.x; c[5] = y.y; c[6] = y.z; c[7] = y.w;
+          }
+          // the window is per lane here: one masked comparison per window present
+          int q1 = 0;
+          for (int kk = 0; kk < W; kk++) {
+            const bool mine = have && k == (uint32_t)kk;
+            if (!__any(mine)) continue;
+            const int q1k = W2 ? (kk == 0 ? win0 : win1) : mp->win[kk];
+            const uint32_t shk = opaque_s(2u * (uint32_t)(CL - q1k));
+            uint32_t w2;
+            if (ulen != 0xFFFFFFFFu) w2 = compare(std::true_type{}, (uint32_t)kk, q1k, shk, seg, jx, mine, c);
+            else w2 = compare(std::false_type{}, (uint32_t)kk, q1k, shk, seg, jx, mine, c);
+            if (mine) {
+              w = w2;
+              q1 = q1k;
+            }
           }
           report(w, gene, jx - (uint32_t)q1);
         }
-      }
-      lds_barrier();
-      // ---- phase C: this window's overflow entries as one flat list
-      {
-        const uint32_t tidc = opaque(threadIdx.x);
-        const uint32_t oc = s_oc[tidc];
-        uint32_t total = 0;
-        const uint32_t pre = wg_scan(oc, &total);
-        if (total != 0) {  // uniform
-          s_pref[tidc] = pre;
-          if (tidc == TILE - 1) s_pref[TILE] = total;
-          for (uint32_t e = 0; e < oc && pre + e < MATCH_OWN; e++) s_own[pre + e] = (uint16_t)tidc;
-          lds_barrier();
-          novf += oc;
-          for (uint32_t t0 = 0; t0 < total; t0 += TILE) {
-            const uint32_t t = t0 + tidc;
-            bool ok = t < total;
-            uint32_t seg = 0, z = 0, gene = 0, jx = 0, w = NX_REJECT;
-            if (ok) {
-              if (t < MATCH_OWN) {
-                seg = s_own[t];
-              } else {  // rare: largest seg with s_pref[seg] <= t
-                uint32_t lo = 0, hi = TILE;
-                while (hi - lo > 1) {
-                  const uint32_t mid = (lo + hi) / 2;
-                  if (s_pref[mid] <= t) lo = mid; else hi = mid;
-                }
-                seg = lo;
-              }
-              const uint32_t* __restrict__ pe =
-                  reinterpret_cast<const uint32_t*>(E + ((uint64_t)s_ovf[seg] + (t - s_pref[seg])));
-              const uint2 hd = *reinterpret_cast<const uint2*>(pe);
-              const u32x4_u x = *reinterpret_cast<const u32x4_u*>(pe + 2);
-              const u32x4_u y = *reinterpret_cast<const u32x4_u*>(pe + 6);
-              gene = hd.x;
-              jx = hd.y;
-              uint32_t rr_w[RW];
-#pragma unroll
-              for (int q = 0; q < RW / 4; q++) {
-                const uint4 a = *reinterpret_cast<const uint4*>(&s_rec[seg * RW + 4 * q]);
-                rr_w[4 * q] = a.x; rr_w[4 * q + 1] = a.y; rr_w[4 * q + 2] = a.z; rr_w[4 * q + 3] = a.w;
-              }
-              const int rlen = (int)(rr_w[RW - 1] & 0xFFFFu);
-              ok = ctx_fit(jx, y.w >> 16, q1, ww, rlen, &z);
-              if (ok) {
-                ncmp++;
-                uint32_t exact0 = s_valid[seg];
-                if (z) exact0 &= ~q1zero;
-                const uint32_t budget = rlen < CONF_NM ? s_nm[rlen] : nmiss_tab[rlen];
-                w = ctx_compare<RW, W2>(rr_w, x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w, sh, (uint32_t)k, mp, W, ww, win0,
-                                        win1, exact0, budget, seg);
-              }
-            }
-            report(w, gene, jx - (uint32_t)q1);
-          }
-        }
-        lds_barrier();  // s_oc / s_ovf / s_pref / s_own are reused by the next window
+        wave_lds_sync();  // the owner tables are rewritten by the next chunk
       }
     }
 
     // ---- phase D: per-read selection and the tuples
     {
-      const uint32_t tidd = opaque(threadIdx.x);
-      const int lane = tidd & 63, wid = tidd >> 6;
-      const uint32_t nl = s_nlist;
-      const uint32_t nspill = nl > MATCH_LIST ? nl - MATCH_LIST : 0u;
+      const uint32_t nl = nlist;
+      const uint32_t nspill = nl > MATCH_WLIST ? nl - MATCH_WLIST : 0u;
       const bool spill_ok = nspill <= sregion;
       if (nspill > maxspill) maxspill = nspill;
-      s_cnt[tidd] = 0;
+      if (nspill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's spilled candidates have landed
       if (block_mode) {
-        for (uint32_t t = tidd; t < TILE * (uint32_t)W; t += TILE) {
-          const uint32_t cw = s_wcnt[t];
+        for (uint32_t t = lane; t < WT * (uint32_t)W; t += 64) {
+          const uint32_t cw = wcnt_l[t];
           if (!cw) continue;
-          const uint32_t rl = t / W, kk = t % W;
-          const uint64_t h = mix64(((uint64_t)kk << 32) | s_bb[kk * TILE + rl]);
+          const uint32_t kk = t >> 6;  // counters and buckets share the layout [window][read]
+          const uint64_t h = mix64(((uint64_t)kk << 32) | bb_l[t]);
           if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - MATCH_SKETCH_BITS)], cw);
           else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
         }
       }
-      lds_barrier();
-      const uint32_t mmtol = (uint32_t)mp->mmtol;
-      const bool apply = mp->apply_mmtol != 0;
+      wave_lds_sync();  // phase C is done with s_oc: it becomes cnt / base
+      cnt_l[lane] = 0;
+      wave_lds_sync();
       auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) -> uint32_t {
-        if (j < MATCH_LIST) {
-          *gene = s_lgene[j];
-          *pos = s_lpos[j];
-          return s_lcode[j];
+        if (j < MATCH_WLIST) {
+          *gene = s_lgene[wid][j];
+          *pos = s_lpos[wid][j];
+          return s_lcode[wid][j];
         }
-        const uint4 v = spill[sregion0 + (j - MATCH_LIST)];
-        *gene = v.y;
-        *pos = v.z;
-        return v.x;
+        // written by other lanes of this wave a moment ago: read past the L1
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(spill + sregion0 + (j - MATCH_WLIST));
+        *gene = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *pos = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
-      const uint32_t nuse = spill_ok ? nl : (nl < MATCH_LIST ? nl : MATCH_LIST);
-      if (nspill) __threadfence_block();
-      for (uint32_t j = tidd; j < nuse; j += TILE) {
+      const uint32_t nuse = spill_ok ? nl : (nl < MATCH_WLIST ? nl : MATCH_WLIST);
+      for (uint32_t j = lane; j < nuse; j += 64) {
         uint32_t g, p;
         const uint32_t w = item(j, &g, &p);
         const uint32_t rl = w >> 24;
-        const uint32_t thr = apply ? s_best[rl] + mmtol : 0xFFFFu;
-        if ((w & 0xFFFFu) <= thr) atomicAdd(&s_cnt[rl], 1u);
+        const uint32_t thr = apply ? s_best[wid][rl] + mmtol : 0xFFFFu;
+        if ((w & 0xFFFFu) <= thr) atomicAdd(&cnt_l[rl], 1u);
       }
-      lds_barrier();
-      const uint32_t cnum = s_cnt[tidd];
-      uint32_t inc = cnum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-      }
-      if (lane == 63) s_wsum[wid] = inc;
-      lds_barrier();
-      uint32_t woff = 0, total = 0;
-#pragma unroll
-      for (int q = 0; q < TILE / 64; q++) {
-        if (q < wid) woff += s_wsum[q];
-        total += s_wsum[q];
-      }
-      s_base[tidd] = woff + inc - cnum;
-      s_cnt[tidd] = 0;  // now the arrival counter of the read
+      wave_lds_sync();
+      const uint32_t cnum = cnt_l[lane];
+      const uint32_t inc = wave_scan_incl(cnum);
+      const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
+      base_l[lane] = inc - cnum;
+      cnt_l[lane] = 0;  // now the arrival counter of the read
       const uint64_t base = region0 + used;
       const bool fits = spill_ok && used + total <= region;
-      if (tidd == 0) {
-        tbase[tile] = (uint32_t)base;
-        tcount2[tile] = fits ? total : 0u;
+      if (lane == 0) {
+        tbase[wt] = (uint32_t)base;
+        tcount2[wt] = fits ? total : 0u;
       }
-      lds_barrier();
+      wave_lds_sync();
       if (fits && total) {
-        for (uint32_t j = tidd; j < nuse; j += TILE) {
+        for (uint32_t j = lane; j < nuse; j += 64) {
           uint32_t g, p;
           const uint32_t w = item(j, &g, &p);
           const uint32_t rl = w >> 24, v = w & 0xFFFFu;
-          const uint32_t thr = apply ? s_best[rl] + mmtol : 0xFFFFu;
+          const uint32_t thr = apply ? s_best[wid][rl] + mmtol : 0xFFFFu;
           if (v > thr) continue;
-          const uint32_t ord = atomicAdd(&s_cnt[rl], 1u);
-          stage[base + s_base[rl] + ord] = make_uint4((uint32_t)(r0 + tile * TILE + rl), g, p, v);
+          const uint32_t ord = atomicAdd(&cnt_l[rl], 1u);
+          stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt * WT + rl), g, p, v);
         }
       }
       used += total;
-      lds_barrier();  // the next tile resets the LDS state
+      wave_lds_sync();  // the next wave-tile rewrites the LDS state
     }
   }
   block_add_u64(nvalid, &counters[8 + 0]);
@@ -574,7 +697,7 @@ __global__ __launch_bounds__(TILE, 5) void k_match(const uint32_t* __restrict__ 
   block_add_u64(ncand, &counters[8 + 3]);
   block_add_u64(novf, &counters[8 + 4]);
   block_add_u64(nrep, &counters[1]);
-  if (threadIdx.x == 0) {
+  if ((threadIdx.x & 63) == 0) {
     atomicAdd(&counters[8 + 6], (unsigned long long)(used <= region ? used : 0));
     atomicMax(&counters[8 + 7], (unsigned long long)used);
     atomicMax(&counters[8 + 5], (unsigned long long)maxspill);
@@ -582,9 +705,30 @@ __global__ __launch_bounds__(TILE, 5) void k_match(const uint32_t* __restrict__ 
     if (maxspill > sregion) atomicOr(&counters[3], 4ull);
   }
   if (block_mode == 1) {
-    lds_barrier();
+    __syncthreads();
     uint32_t hot = 0;
     for (uint32_t t = threadIdx.x; t < (1u << MATCH_SKETCH_BITS); t += TILE) hot |= s_sketch[t] >= block_thr;
     if (__any(hot) && (threadIdx.x & 63) == 0) atomicOr(&counters[6], 1ull);
+  }
+}
+
+// k_compact_w -- hits[counters[2] + tpre[wt] ...] = the wave-tile's staged tuples (tpre = scan of
+// tcount2), a wave per wave-tile: plain 16-byte copies, contiguous on both sides.
+__global__ __launch_bounds__(256) void k_compact_w(uint32_t nwt, const uint32_t* __restrict__ tbase,
+                                                   const uint32_t* __restrict__ tcount2,
+                                                   const uint32_t* __restrict__ tpre, const uint4* __restrict__ stage,
+                                                   uint4* __restrict__ hits, uint64_t hits_cap,
+                                                   unsigned long long* __restrict__ counters) {
+  const unsigned long long base = counters[2];
+  if (base + tpre[nwt] > hits_cap) {  // cannot happen on a sized pass; a sync-free pass re-runs sized
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&counters[3], 2ull);
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t wt = blockIdx.x * 4 + (threadIdx.x >> 6); wt < nwt; wt += gridDim.x * 4) {
+    const uint32_t m = tcount2[wt];
+    const uint4* __restrict__ src = stage + tbase[wt];
+    uint4* __restrict__ dst = hits + base + tpre[wt];
+    for (uint32_t j = lane; j < m; j += 64) dst[j] = src[j];
   }
 }

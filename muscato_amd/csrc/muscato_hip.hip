@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/muscato_hip.h"
@@ -940,7 +941,7 @@ extern "C++" {
 template <int RW>
 static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr) {
   const dim3 grid(std::min(nblk(n, TILE), MAX_GRID)), block(TILE);
-  const size_t lds = block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;
+  const size_t lds = block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;  // TILE = 4 waves x 64
 #define MUSC_LAUNCH_MATCH(W2)                                                                                     \
   hipLaunchKernelGGL((k_match<RW, W2>), grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,       \
                      c->ctx_T, c->ctx_E, c->stage.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,    \
@@ -955,12 +956,14 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
   int rc = 0;
   if (c->rw != 4 && c->rw != 8 && c->rw != 12) return fail(c, 12, "internal: record stride %d on the context path", c->rw);
   {
-    MatchParams mp;
+    static thread_local MatchParams mp;  // 16 KB with its mask tables: not on the stack
     memset(&mp, 0, sizeof mp);
     mp.W = pp.W; mp.ww = pp.ww; mp.min_dinuc = pp.min_dinuc; mp.bits = pp.bits; mp.direct = pp.direct;
     mp.mmtol = pp.mmtol; mp.apply_mmtol = pp.apply_mmtol; mp.max_len = pp.max_len; mp.CL = c->idx_CL;
     mp.q1zero_mask = pp.q1zero_mask;
+    if (const char* dv = getenv("MUSC_DEBUG_MATCH")) mp.dbg = atoi(dv);
     for (int k = 0; k < pp.W && k < CTX_MAX_W; k++) mp.win[k] = pp.win[k];
+    match_tables(mp);
     if (!c->h_mp_valid || memcmp(&mp, &c->h_mp, sizeof mp) != 0) {
       c->h_mp = mp;
       HIPCHK(c, hipMemcpyAsync(c->d_mp, &c->h_mp, sizeof mp, hipMemcpyHostToDevice, c->stream));
@@ -987,15 +990,16 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     bool again = false;
     while (r0 < c->nreads) {
       const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
-      const uint32_t ntiles = nblk(n, TILE);
+      const uint32_t ntiles = nblk(n, WT);  // wave-tiles of 64 reads
       const uint64_t sgrid = std::min(nblk(n, TILE), MAX_GRID);
+      const uint64_t swaves = sgrid * (TILE / 64);  // regions of stage and spill are per wave
       if (!sized) {
         if ((rc = ensure(c, c->bs[0].tbase, (uint64_t)ntiles + 1))) return rc;
         if ((rc = ensure(c, c->scan_tmp, scan_tmp_elems((uint64_t)ntiles + 1)))) return rc;
         if ((rc = ensure(c, c->tcount2, (uint64_t)ntiles + 1))) return rc;
         if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
-        if ((rc = ensure(c, c->stage, std::max<uint64_t>(2ull * n, sgrid * 64)))) return rc;
-        if ((rc = ensure(c, c->spill, sgrid * 64))) return rc;
+        if ((rc = ensure(c, c->stage, std::max<uint64_t>(2ull * n, swaves * 64)))) return rc;
+        if ((rc = ensure(c, c->spill, swaves * 16))) return rc;
         HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
       }
       tm.begin(0);
@@ -1011,7 +1015,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       if (!sized) {
         HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters, 16 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint64_t need_stage = c->h_pinned[8 + 7] * sgrid, need_spill = c->h_pinned[8 + 5] * sgrid;
+        const uint64_t need_stage = c->h_pinned[8 + 7] * swaves, need_spill = c->h_pinned[8 + 5] * swaves;
         if (need_stage > (1ull << 31)) {  // u32 tuple offsets within a batch: retry with half the reads
           if (n == 1) return fail(c, 6, "one read has %llu tuples (> 2^31)", (unsigned long long)c->h_pinned[8 + 7]);
           bsz = n / 2;
@@ -1021,8 +1025,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         if (c->h_pinned[3] || need_stage > c->stage.cap || need_spill > c->spill.cap) {
           // room for every workgroup's tuples / spilled candidates, then the pass starts over
           // (k_match has already added this batch to the pass-level counters)
-          if (need_stage > c->stage.cap && (rc = ensure(c, c->stage, need_stage + need_stage / 4 + sgrid))) return rc;
-          if (need_spill > c->spill.cap && (rc = ensure(c, c->spill, need_spill + need_spill / 4 + sgrid))) return rc;
+          if (need_stage > c->stage.cap && (rc = ensure(c, c->stage, need_stage + need_stage / 4 + swaves))) return rc;
+          if (need_spill > c->spill.cap && (rc = ensure(c, c->spill, need_spill + need_spill / 4 + swaves))) return rc;
           again = true;
           break;
         }
@@ -1037,7 +1041,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p, c->stream);
       if (rc) return rc;
       tm.end(1);
-      hipLaunchKernelGGL(k_compact, dim3((unsigned)sgrid), dim3(256), 0, c->stream, ntiles, c->bs[0].tbase.p, c->tcount2.p,
+      hipLaunchKernelGGL(k_compact_w, dim3((unsigned)sgrid), dim3(256), 0, c->stream, ntiles, c->bs[0].tbase.p, c->tcount2.p,
                          c->tpre.p, c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap, c->counters);
       HIPCHK(c, hipGetLastError());
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->tpre.p, ntiles, c->counters);
