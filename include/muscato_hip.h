@@ -219,6 +219,16 @@ void musc_free_u32(uint32_t* p);
  * over RCCL instead: muscato_amd/dist.py.) */
 int musc_gather(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hit** hits,
                 uint64_t* nhits);
+/* The same over RCCL: the tuples of ctxs[1..n) travel to ctxs[0]'s GPU over xGMI (ncclSend /
+ * ncclRecv, all of them in one ncclGroupStart/End so that the links run side by side), are
+ * rebased there and leave the node's GPUs in ONE device-to-host copy -- the concatenation step
+ * of the reference (combineWindows, cmd/muscato/main.go:422-505) without N host copies.  One
+ * clique per device list is created on first use (ncclCommInitAll) and kept for the process.
+ * librccl is loaded at run time on the first call with n > 1: a return code of 20 means it
+ * could not be used (the text says why) and musc_gather is the alternative.  The contexts must
+ * sit on distinct devices. */
+int musc_gather_rccl(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hit** hits,
+                     uint64_t* nhits);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,6 @@ the host-side mirror of the reference interface (api.Config / api.Engine).  Impo
 package does not load the HIP library; creating an Engine does, and fails loudly if
 libmuscato_hip.so is missing (no CPU fallback).
 """
-from .api import Config, Engine, MuscatoError, sorted_hits  # noqa: F401
+from .api import Config, Engine, MuscatoError, gather, sorted_hits  # noqa: F401
 
-__all__ = ["Config", "Engine", "MuscatoError", "sorted_hits"]
+__all__ = ["Config", "Engine", "MuscatoError", "gather", "sorted_hits"]

@@ -55,7 +55,7 @@ def build_tools(force: bool = False, verbose: bool = False) -> None:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
+               "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -943,15 +943,35 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
   if (err.empty()) {
     musc_hit* h = nullptr;
     uint64_t n = 0;
-    if (musc_gather(ctxs.data(), G, base.data(), &h, &n)) err = musc_last_error(ctxs[0]);
+    // the shards' tuples meet on the first GPU over RCCL/xGMI and leave it in one copy; without
+    // a usable librccl (return code 20) every GPU copies its own to the host instead
+    int grc = G > 1 ? musc_gather_rccl(ctxs.data(), G, base.data(), &h, &n) : musc_gather(ctxs.data(), G, base.data(), &h, &n);
+    if (grc == 20) {
+      log.printf("RCCL gather unavailable (%s): gathering through the host", musc_last_error(ctxs[0]));
+      grc = musc_gather(ctxs.data(), G, base.data(), &h, &n);
+    } else if (G > 1 && grc == 0) {
+      log.printf("tuples of %d GPUs gathered on GPU %d over RCCL", G, cfg.Device);
+    }
+    if (grc) err = musc_last_error(ctxs[0]);
     else {
       out.assign(h, h + n);
       musc_free_hits(h);
     }
     if (stats0) musc_get_stats(ctxs[0], stats0);
+    std::string prof = "[";
     for (int g = 0; g < G; g++) {
       musc_stats s;
       musc_get_stats(ctxs[g], &s);
+      char pb[1024];
+      snprintf(pb, sizeof pb,
+               "%s{\"gpu\":%d,\"index_kind\":%u,\"index_bytes\":%llu,\"reads\":%llu,\"read_windows\":%llu,\"index_entries_walked\":%llu,"
+               "\"pairs_compared\":%llu,\"accepted\":%llu,\"tuples\":%llu,\"batches\":%u,\"ms_total\":%.4f,\"ms_screen_or_match\":%.4f,"
+               "\"ms_confirm\":%.4f,\"ms_scan\":%.4f,\"ms_compact\":%.4f,\"ms_index_build\":%.3f,\"confirm_bytes\":%llu,\"match_bytes\":%llu}",
+               g ? "," : "", cfg.Device + g, s.index_kind, (unsigned long long)s.index_bytes, (unsigned long long)s.n_reads,
+               (unsigned long long)s.n_read_windows, (unsigned long long)s.n_candidates, (unsigned long long)s.n_pairs,
+               (unsigned long long)s.n_accepted, (unsigned long long)s.n_hits, s.n_batches, s.ms_total, s.ms_screen, s.ms_confirm,
+               s.ms_scan, s.ms_select, s.ms_index_build, (unsigned long long)s.confirm_bytes, (unsigned long long)s.match_bytes);
+      prof += pb;
       log.printf("gpu %d: reads %llu windows %llu candidates %llu pairs %llu accepted %llu hits %llu; device %.3f ms "
                  "(screen %.3f scan %.3f confirm %.3f select %.3f), index build %.1f ms, confirm %.1f GB/s",
                  cfg.Device + g, (unsigned long long)s.n_reads, (unsigned long long)s.n_read_windows,
@@ -959,6 +979,9 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
                  (unsigned long long)s.n_hits, s.ms_total, s.ms_screen, s.ms_scan, s.ms_confirm, s.ms_select,
                  s.ms_index_build, s.ms_confirm > 0 ? s.confirm_bytes / 1e6 / s.ms_confirm : 0.0);
     }
+    // --CPUProfile (cmd/muscato_screen/main.go:530-538 writes a pprof CPU profile of the screen to
+    // LogDir): here the hot path runs on the GPU, so the profile is the per-kernel device timing
+    if (cfg.CPUProfile) spit(join_path(cfg.LogDir, "muscato_gpu_profile.json"), prof + "]\n");
   }
   bool overflow = false;
   for (int g = 0; g < G && err.empty(); g++) {
@@ -1066,6 +1089,16 @@ inline int run_muscato(Config cfg) {
   Logger log;
   log.open(join_path(cfg.LogDir, "muscato.log"));
   spit(join_path(cfg.LogDir, "config.json"), config_to_json(cfg));
+  // cleanTmp is deferred in the reference (cmd/muscato/main.go:969-979, 1019): the temporary
+  // directory goes away on every exit path, also when a stage fails, unless NoCleanTemp is set
+  struct TmpGuard {
+    const Config& c;
+    ~TmpGuard() {
+      if (c.NoCleanTemp) return;
+      unlink(join_path(c.TempDir, "reads_sorted.txt.sz").c_str());
+      rmdir(c.TempDir.c_str());
+    }
+  } tmp_guard{cfg};
 
   StageClock clk(log);
   fputs("Preparing reads...\n", stderr);
@@ -1094,6 +1127,22 @@ inline int run_muscato(Config cfg) {
   // (cmd/muscato_screen/main.go:439-452); id file: "%011d\tname\tlen" (join field 1)
   std::vector<std::string> targets;
   for (auto& l : split_lines(read_maybe_sz(cfg.GeneFileName))) targets.push_back(l.substr(0, l.find('\t')));
+  {
+    // Targets are compared as 2-bit bases + an "X" plane: every byte that is not A, C, G or T is an
+    // X here.  muscato_prep_targets writes nothing else (it leaves the LAST FASTA record un-substituted,
+    // cmd/muscato_prep_targets/main.go:204-212), but a hand-made gene file may: the reference then
+    // compares the raw byte, so an 'N' in a target would mismatch an 'X' in a read where this tool
+    // counts a match.  Say so instead of differing silently.
+    size_t nodd = 0, first_t = 0;
+    for (size_t t = 0; t < targets.size(); t++)
+      for (unsigned char ch : targets[t])
+        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'X' && nodd++ == 0) first_t = t;
+    if (nodd) {
+      fprintf(stderr, "Warning: %zu target bytes are none of ACGTX (first in target %zu); they are treated as X\n", nodd, first_t);
+      log.printf("%zu target bytes are none of ACGTX (first in target %zu): treated as X; the reference compares them "
+                 "literally, so they would mismatch an X of a read there", nodd, first_t);
+    }
+  }
   std::map<uint64_t, std::string> id_rest;
   for (auto& l : split_lines(read_maybe_sz(cfg.GeneIdFileName))) {
     size_t t = l.find('\t');
@@ -1132,10 +1181,6 @@ inline int run_muscato(Config cfg) {
     for (auto& e : err_side) if (!e.empty()) throw Die(1, "side output: " + e);
   }
   clk.lap("nonmatch + stats files");
-  if (!cfg.NoCleanTemp) {  // cleanTmp (cmd/muscato/main.go:969-979)
-    unlink(join_path(cfg.TempDir, "reads_sorted.txt.sz").c_str());
-    rmdir(cfg.TempDir.c_str());
-  }
   return 0;
 }
 

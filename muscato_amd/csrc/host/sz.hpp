@@ -192,7 +192,13 @@ inline std::string gz_decode_file(const std::string& path) {
 // and as every reference tool does for its inputs).
 inline std::string read_maybe_sz(const std::string& path) {
   std::string raw = slurp(path);
-  if (ends_with(to_lower(path), ".sz")) return sz_decode(raw);
+  // A framed snappy stream says so itself: stream identifier chunk ff 06 00 00 "sNaPpY".  The
+  // reference reads its inputs through snappy.NewReader whatever they are called
+  // (cmd/muscato_screen/main.go:417), so the name must not decide; a file named .sz that is not
+  // a snappy stream fails in sz_decode, as it fails there.
+  static const char magic[10] = {(char)0xff, 0x06, 0x00, 0x00, 's', 'N', 'a', 'P', 'p', 'Y'};
+  const bool is_stream = raw.size() >= sizeof magic && memcmp(raw.data(), magic, sizeof magic) == 0;
+  if (is_stream || ends_with(to_lower(path), ".sz")) return sz_decode(raw);
   return raw;
 }
 

@@ -186,12 +186,13 @@ __global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void
     const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm,
     const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2, const uint32_t* __restrict__ dbx,
     uint64_t r0, uint32_t n, int rw_rt,
-    PathParams pp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
+    const PathParams* __restrict__ ppp, const uint16_t* __restrict__ nmiss_tab, const uint4* __restrict__ cdesc,
     const uint32_t* __restrict__ rvalid, uint32_t* __restrict__ p_nx,
     const uint32_t* __restrict__ tbase, const uint32_t* __restrict__ tcount,
     const uint32_t* __restrict__ wb, int block_mode, uint32_t block_thr, uint32_t* __restrict__ block_table,
     const uint64_t* __restrict__ seq_off, uint4* __restrict__ stage, uint32_t* __restrict__ tcount2,
     unsigned long long* __restrict__ counters) {
+  const PathParams& pp = *ppp;  // read where used (scalar loads), see k_screen
   extern __shared__ uint32_t s_wcnt[];  // TILE * W counters when block_mode != 0
   __shared__ uint32_t s_best[TILE], s_cnt[TILE], s_base[TILE];
   __shared__ uint32_t s_code[CODE_CAP];
@@ -357,10 +358,11 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t ntiles, const uint32_t
 template <int RW>
 __global__ __launch_bounds__(256) void k_hot_probes(const uint32_t* __restrict__ rd,
                                                     const uint32_t* __restrict__ rdm, uint64_t nreads,
-                                                    int rw_rt, PathParams pp,
+                                                    int rw_rt, const PathParams* __restrict__ ppp,
                                                     const uint32_t* __restrict__ block_table,
                                                     uint32_t max_matches, uint2* __restrict__ out,
                                                     uint64_t cap, unsigned long long* __restrict__ cursor) {
+  const PathParams& pp = *ppp;
   const int rw = RW ? RW : rw_rt;
   const bool has_m = rdm != nullptr;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nreads; i += (uint64_t)gridDim.x * blockDim.x) {

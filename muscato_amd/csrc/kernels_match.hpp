@@ -692,17 +692,44 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       wave_lds_sync();  // the next wave-tile rewrites the LDS state
     }
   }
-  block_add_u64(nvalid, &counters[8 + 0]);
-  block_add_u64(ncmp, &counters[8 + 1]);
-  block_add_u64(ncand, &counters[8 + 3]);
-  block_add_u64(novf, &counters[8 + 4]);
-  block_add_u64(nrep, &counters[1]);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&counters[8 + 6], (unsigned long long)(used <= region ? used : 0));
-    atomicMax(&counters[8 + 7], (unsigned long long)used);
-    atomicMax(&counters[8 + 5], (unsigned long long)maxspill);
-    if (used > region) atomicOr(&counters[3], 1ull);
-    if (maxspill > sregion) atomicOr(&counters[3], 4ull);
+  // One reduction per workgroup and a handful of atomics from its first thread: atomics on one
+  // address serialise at about 90 M/s on this GPU, so per-wave atomics from a large grid would
+  // cost more than the kernel (the grid is also kept to the waves that are resident at once).
+  {
+    __shared__ unsigned long long s_red[NWAVE][8];
+    unsigned long long v[5] = {nvalid, ncmp, ncand, novf, nrep};
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+      for (int d = 32; d; d >>= 1) v[q] += __shfl_xor(v[q], d);
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 5; q++) s_red[wv][q] = v[q];
+      s_red[wv][5] = used <= region ? used : 0;
+      s_red[wv][6] = used;
+      s_red[wv][7] = ((unsigned long long)(used > region) << 32) | maxspill;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long t[6] = {0, 0, 0, 0, 0, 0}, mx_used = 0, mx_spill = 0, over = 0;
+      for (int w = 0; w < NWAVE; w++) {
+        for (int q = 0; q < 6; q++) t[q] += s_red[w][q];
+        mx_used = s_red[w][6] > mx_used ? s_red[w][6] : mx_used;
+        const unsigned long long sp = s_red[w][7] & 0xFFFFFFFFull;
+        mx_spill = sp > mx_spill ? sp : mx_spill;
+        over |= s_red[w][7] >> 32;
+      }
+      if (t[0]) atomicAdd(&counters[8 + 0], t[0]);
+      if (t[1]) atomicAdd(&counters[8 + 1], t[1]);
+      if (t[2]) atomicAdd(&counters[8 + 3], t[2]);
+      if (t[3]) atomicAdd(&counters[8 + 4], t[3]);
+      if (t[4]) atomicAdd(&counters[1], t[4]);
+      if (t[5]) atomicAdd(&counters[8 + 6], t[5]);
+      atomicMax(&counters[8 + 7], mx_used);
+      if (mx_spill) atomicMax(&counters[8 + 5], mx_spill);
+      if (over) atomicOr(&counters[3], 1ull);
+      if (mx_spill > sregion) atomicOr(&counters[3], 4ull);
+    }
   }
   if (block_mode == 1) {
     __syncthreads();

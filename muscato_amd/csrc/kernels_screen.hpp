@@ -217,7 +217,7 @@ DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values der
 template <int RW, bool MASK, bool ONE>
 __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen(const uint32_t* __restrict__ rd,
                                                  const uint32_t* __restrict__ rdm, uint64_t r0,
-                                                 uint32_t n, int rw_rt, PathParams pp,
+                                                 uint32_t n, int rw_rt, const PathParams* __restrict__ ppp,
                                                  const uint16_t* __restrict__ nmiss_tab,
                                                  const Bucket* __restrict__ T,
                                                  const uint4* __restrict__ E,
@@ -239,6 +239,9 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
   // entries owns c consecutive items): every load is independent and they are issued together.
   // The workgroup keeps little LDS (18 KB) so that eight of them share a CU and one
   // workgroup's memory round trips hide behind the others' arithmetic.
+  // the run's parameters stay in device memory and are read (scalar loads) where they are used: a
+  // by-value block of 28 words lived in scalar registers for the whole kernel and spilled 64 of them
+  const PathParams& pp = *ppp;
   __shared__ uint32_t s_wsum[TILE / 64];
   __shared__ uint32_t s_bb[SCR_PROBES];        // per probe: bucket, WB_NONE when the window takes no part
   __shared__ uint32_t s_rfl[SCR_PROBES];       // per probe: the read's own 8+8 flanking bases

@@ -20,12 +20,16 @@
 // There is no CPU fallback in this library.
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is resolved at run time (rccl_api)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -54,6 +58,38 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+  }
+};
+
+// roctx ranges around the kernel families (the reference's tracing hook is the
+// CPUProfile flag, cmd/muscato_screen/main.go:530-538): visible in `rocprofv3 --marker-trace`.
+// The marker library is resolved at run time; without it the ranges are no-ops.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr;
+        pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(roctx().push != nullptr) {
+    if (on) (void)roctx().push(name);
+  }
+  ~Range() {
+    if (on) (void)roctx().pop();
   }
 };
 
@@ -109,6 +145,9 @@ struct musc_ctx {
   CtxBucket* ctx_T = nullptr;
   CtxEntry* ctx_E = nullptr;
   uint64_t ctx_T_cap = 0, ctx_E_cap = 0;
+  PathParams* d_pp = nullptr;   // k_screen / k_confirm / k_hot_probes: the run's parameters
+  PathParams h_pp;              // what d_pp holds
+  bool h_pp_valid = false;
   MatchParams* d_mp = nullptr;  // k_match's parameter block
   MatchParams h_mp;             // what d_mp holds
   bool h_mp_valid = false;
@@ -149,6 +188,7 @@ struct musc_ctx {
   DevBuf<musc_hit> hits;
   uint64_t nhits = 0;
   DevBuf<uint64_t> packed;      // staging of musc_hits_copy_packed / musc_hits_unpack for host pointers
+  DevBuf<musc_hit> gathered;    // musc_gather_rccl: every context's tuples on this device
   uint32_t* d_flag = nullptr;   // one device word for kernels that report "does not fit"
 
   uint32_t batch_reads = 16u << 20;
@@ -363,7 +403,7 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
   if (stage == 0) {
     const dim3 sgrid(std::min(nblk(n, TILE), MAX_GRID));
 #define MUSC_LAUNCH_SCREEN(M, O)                                                                                  \
-    hipLaunchKernelGGL((k_screen<RW, M, O>), sgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, pp,          \
+    hipLaunchKernelGGL((k_screen<RW, M, O>), sgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, c->d_pp,     \
                        c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,        \
                        c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, \
                        c->counters + 8)
@@ -378,7 +418,7 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
     const size_t lds = c->cur_block_mode ? (size_t)TILE * pp.W * 4 : 0;
 #define MUSC_LAUNCH_CONFIRM(M, W2)                                                                                 \
     hipLaunchKernelGGL((k_confirm<RW, M, W2>), grid, block, lds, c->s_confirm, c->rd, c->rdm, c->db2, c->dbm2,      \
-                       c->dbx, r0, n, c->rw, pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p,     \
+                       c->dbx, r0, n, c->rw, c->d_pp, c->nmiss_tab.p, c->bs[c->cur].cdesc.p, c->bs[c->cur].rvalid.p,     \
                        c->p_nx.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, c->bs[c->cur].wb.p,                \
                        c->cur_block_mode, c->cur_block_thr, c->block_table.p, c->seq_off, c->stage.p, c->tcount2.p, \
                        c->counters)
@@ -438,6 +478,7 @@ int musc_init(int device_ordinal, musc_ctx** out) {
       (e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long))) != hipSuccess ||
       (e = hipMalloc((void**)&c->d_flag, 4)) != hipSuccess ||
       (e = hipMalloc((void**)&c->d_mp, sizeof(MatchParams))) != hipSuccess ||
+      (e = hipMalloc((void**)&c->d_pp, sizeof(PathParams))) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(uint64_t))) != hipSuccess) {
     fail(nullptr, 3, "musc_init: %s", hipGetErrorString(e));
     musc_destroy(c);
@@ -463,6 +504,7 @@ void musc_destroy(musc_ctx* c) {
   if (c->ctx_T) (void)hipFree(c->ctx_T);
   if (c->ctx_E) (void)hipFree(c->ctx_E);
   if (c->d_mp) (void)hipFree(c->d_mp);
+  if (c->d_pp) (void)hipFree(c->d_pp);
   c->spill.release();
   for (int i = 0; i < 2; i++) {
     c->bs[i].wb.release(); c->bs[i].tbase.release(); c->bs[i].rvalid.release(); c->bs[i].tcount.release();
@@ -474,6 +516,7 @@ void musc_destroy(musc_ctx* c) {
   c->block_table.release();
   c->hits.release();
   c->packed.release();
+  c->gathered.release();
   if (c->d_flag) (void)hipFree(c->d_flag);
   if (c->counters) (void)hipFree(c->counters);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -938,10 +981,27 @@ int musc_reads_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t*
 // start over with larger buffers), later passes run without host round trips and check the
 // guards once at the end -- the same protocol as the two-kernel path below.
 extern "C++" {
+static size_t match_dyn_lds(int W, int block_mode) {
+  return block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;  // TILE = 4 waves x 64
+}
+
+// workgroups of k_match that are resident at once on this device: the persistent grid
 template <int RW>
-static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr) {
-  const dim3 grid(std::min(nblk(n, TILE), MAX_GRID)), block(TILE);
-  const size_t lds = block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;  // TILE = 4 waves x 64
+static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
+  int per_cu = 0, ncu = 0;
+  const size_t lds = match_dyn_lds(W, block_mode);
+  hipError_t e = w2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, true>, TILE, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, false>, TILE, lds);
+  if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+  return (unsigned)per_cu * (unsigned)ncu;
+}
+
+template <int RW>
+static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr,
+                         unsigned ngrid) {
+  const dim3 grid(ngrid), block(TILE);
+  const size_t lds = match_dyn_lds(W, block_mode);
 #define MUSC_LAUNCH_MATCH(W2)                                                                                     \
   hipLaunchKernelGGL((k_match<RW, W2>), grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,       \
                      c->ctx_T, c->ctx_E, c->stage.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,    \
@@ -951,10 +1011,22 @@ static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, i
 }
 }  // extern "C++"
 
-static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& pp, int block_mode, uint32_t block_thr,
+static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& pp, int block_mode, uint32_t block_thr_unused,
                           uint64_t max_matches, uint64_t planned_batches, uint64_t* nhits) {
   int rc = 0;
   if (c->rw != 4 && c->rw != 8 && c->rw != 12) return fail(c, 12, "internal: record stride %d on the context path", c->rw);
+  (void)block_thr_unused;
+  // the persistent grid = the workgroups that are resident at once (every wave then sees many
+  // wave-tiles and the end-of-kernel atomics stay few); the MaxMatches screening threshold is per
+  // workgroup-launch, so it follows the grid
+  const unsigned resident = c->rw == 4 ? match_resident<4>(c, pp.W <= 2, pp.W, block_mode)
+                            : c->rw == 8 ? match_resident<8>(c, pp.W <= 2, pp.W, block_mode)
+                                         : match_resident<12>(c, pp.W <= 2, pp.W, block_mode);
+  uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * resident), 0x7FFFFFFFull);
+  if (block_mode == 1 && block_thr < 2) block_mode = 2;
+  if (block_mode == 2 && !c->block_table.p) {
+    if ((rc = ensure(c, c->block_table, 1ull << BLOCK_TABLE_BITS))) return rc;
+  }
   {
     static thread_local MatchParams mp;  // 16 KB with its mask tables: not on the stack
     memset(&mp, 0, sizeof mp);
@@ -991,7 +1063,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     while (r0 < c->nreads) {
       const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
       const uint32_t ntiles = nblk(n, WT);  // wave-tiles of 64 reads
-      const uint64_t sgrid = std::min(nblk(n, TILE), MAX_GRID);
+      const uint64_t sgrid = std::min<uint64_t>(nblk(n, TILE), resident);
       const uint64_t swaves = sgrid * (TILE / 64);  // regions of stage and spill are per wave
       if (!sized) {
         if ((rc = ensure(c, c->bs[0].tbase, (uint64_t)ntiles + 1))) return rc;
@@ -1003,10 +1075,13 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
       }
       tm.begin(0);
+      {
+        Range rg("k_match");
       switch (c->rw) {
-        case 4: launch_match<4>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr); break;
-        case 8: launch_match<8>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr); break;
-        default: launch_match<12>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr); break;
+        case 4: launch_match<4>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid); break;
+        case 8: launch_match<8>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid); break;
+        default: launch_match<12>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid); break;
+      }
       }
       HIPCHK(c, hipGetLastError());
       tm.end(0);
@@ -1036,12 +1111,13 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         n_ovf += c->h_pinned[8 + 4];
         if ((rc = ensure(c, c->hits, c->h_pinned[2] + c->h_pinned[8 + 6], true))) return rc;
       }
+      Range rgc("scan + k_compact_w");
       tm.begin(4);
       tm.begin(1);
       rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p, c->stream);
       if (rc) return rc;
       tm.end(1);
-      hipLaunchKernelGGL(k_compact_w, dim3((unsigned)sgrid), dim3(256), 0, c->stream, ntiles, c->bs[0].tbase.p, c->tcount2.p,
+      hipLaunchKernelGGL(k_compact_w, dim3(std::min(nblk(ntiles, 4), 4u * MAX_GRID)), dim3(256), 0, c->stream, ntiles, c->bs[0].tbase.p, c->tcount2.p,
                          c->tpre.p, c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap, c->counters);
       HIPCHK(c, hipGetLastError());
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->tpre.p, ntiles, c->counters);
@@ -1105,6 +1181,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
 
 int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   if (!c) return 1;
+  Range rg_pass("musc_match_device");
   int rc = check_params(c, P);
   if (rc) return rc;
   if (!c->db2) return fail(c, 4, "no database loaded");
@@ -1172,6 +1249,12 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   if (block_mode == 2) {
     if ((rc = ensure(c, c->block_table, 1ull << BLOCK_TABLE_BITS))) return rc;
     HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
+  }
+  if (!c->h_pp_valid || memcmp(&pp, &c->h_pp, sizeof pp) != 0) {
+    c->h_pp = pp;
+    HIPCHK(c, hipMemcpyAsync(c->d_pp, &c->h_pp, sizeof pp, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_pp_valid = true;
   }
   c->stats.index_kind = (uint32_t)c->idx_kind;
   c->stats.index_bytes = c->idx_kind == 1
@@ -1251,7 +1334,10 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     }
 
     tm.begin(0);
-    launch_stage(c, 0, mask, r0, n, pp);
+    {
+      Range rg("k_screen");
+      launch_stage(c, 0, mask, r0, n, pp);
+    }
     HIPCHK(c, hipGetLastError());
     tm.end(0);
     if (piped) {
@@ -1292,11 +1378,15 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       const dim3 sg(std::min(nblk(n, TILE), MAX_GRID));
 
       tm.begin(3, sB);
-      launch_stage(c, 2, mask, r0, n, pp);
+      {
+        Range rg("k_confirm");
+        launch_stage(c, 2, mask, r0, n, pp);
+      }
       HIPCHK(c, hipGetLastError());
       tm.end(3, sB);
       c->stats.confirm_launches++;
 
+      Range rgc("scan + k_compact");
       tm.begin(4, sB);
       tm.begin(1, sB);
       rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p, sB);
@@ -1509,11 +1599,11 @@ int musc_overflow_probes(musc_ctx* c, uint32_t** read_idx, uint32_t** window, ui
     HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8, c->stream));
     const dim3 grid(std::min(nblk(c->nreads, 256), MAX_GRID)), block(256);
     switch (c->rw) {
-      case 4: hipLaunchKernelGGL((k_hot_probes<4>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
-      case 8: hipLaunchKernelGGL((k_hot_probes<8>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
-      case 12: hipLaunchKernelGGL((k_hot_probes<12>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
-      case 16: hipLaunchKernelGGL((k_hot_probes<16>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
-      default: hipLaunchKernelGGL((k_hot_probes<0>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->last_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      case 4: hipLaunchKernelGGL((k_hot_probes<4>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->d_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      case 8: hipLaunchKernelGGL((k_hot_probes<8>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->d_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      case 12: hipLaunchKernelGGL((k_hot_probes<12>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->d_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      case 16: hipLaunchKernelGGL((k_hot_probes<16>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->d_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
+      default: hipLaunchKernelGGL((k_hot_probes<0>), grid, block, 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->d_pp, c->block_table.p, c->last_max_matches, d_out, cap, c->counters + 8); break;
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_pinned, c->counters + 8, 8, hipMemcpyDeviceToHost, c->stream);
@@ -1573,6 +1663,135 @@ int musc_gather(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hi
     const uint64_t base = read_base ? read_base[i] : 0;
     for (uint64_t j = 0; j < c->nhits; j++) h[o + j].read_idx += (uint32_t)base;
     o += c->nhits;
+  }
+  *hits = h;
+  *nhits = total;
+  return 0;
+}
+
+// ---- RCCL, resolved at run time: a single-GPU user never loads the library, and a box without
+// it still runs everything but musc_gather_rccl
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+  std::map<std::vector<int>, std::vector<ncclComm_t>> comms;  // one clique per device list, kept for the process
+};
+std::mutex g_rccl_mu;
+
+RcclApi* rccl_api() {
+  static RcclApi api;
+  if (api.lib || !api.err.empty()) return &api;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) break;
+  }
+  if (!api.lib) {
+    api.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+    return &api;
+  }
+#define MUSC_RCCL_SYM(FIELD, NAME)                                   \
+  api.FIELD = reinterpret_cast<decltype(api.FIELD)>(dlsym(api.lib, NAME)); \
+  if (!api.FIELD && api.err.empty()) api.err = std::string("librccl lacks ") + NAME;
+  MUSC_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+  MUSC_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+  MUSC_RCCL_SYM(GroupStart, "ncclGroupStart")
+  MUSC_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+  MUSC_RCCL_SYM(Send, "ncclSend")
+  MUSC_RCCL_SYM(Recv, "ncclRecv")
+  MUSC_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef MUSC_RCCL_SYM
+  return &api;
+}
+}  // namespace
+
+__global__ void k_rebase_reads(uint4* __restrict__ h, uint64_t n, uint32_t base) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) h[i].x += base;
+}
+
+int musc_gather_rccl(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hit** hits, uint64_t* nhits) {
+  if (!ctxs || n < 1 || !hits || !nhits) return 1;
+  *hits = nullptr;
+  *nhits = 0;
+  uint64_t total = 0;
+  std::vector<uint64_t> off(n + 1, 0);
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i]) return 1;
+    devs[i] = ctxs[i]->device;
+    off[i] = total;
+    total += ctxs[i]->nhits;
+  }
+  off[n] = total;
+  musc_ctx* c0 = ctxs[0];
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++)
+      if (devs[i] == devs[j]) return fail(c0, 2, "musc_gather_rccl: contexts %d and %d share device %d", i, j, devs[i]);
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  std::vector<ncclComm_t>* comms = nullptr;
+  RcclApi* api = nullptr;
+  if (n > 1) {
+    api = rccl_api();
+    if (!api->err.empty()) return fail(c0, 20, "musc_gather_rccl: %s", api->err.c_str());
+    auto it = api->comms.find(devs);
+    if (it == api->comms.end()) {
+      std::vector<ncclComm_t> cs(n);
+      const ncclResult_t r = api->CommInitAll(cs.data(), n, devs.data());
+      if (r != ncclSuccess) return fail(c0, 20, "musc_gather_rccl: ncclCommInitAll: %s", api->GetErrorString(r));
+      it = api->comms.emplace(devs, cs).first;
+    }
+    comms = &it->second;
+  }
+  HIPCHK(c0, hipSetDevice(c0->device));
+  int rc = ensure(c0, c0->gathered, total ? total : 1);
+  if (rc) return rc;
+  // the destination's own tuples never touch a link; everything else arrives over xGMI, all
+  // transfers in ONE group so that the links run side by side
+  if (c0->nhits)
+    HIPCHK(c0, hipMemcpyAsync(c0->gathered.p, c0->hits.p, c0->nhits * sizeof(musc_hit), hipMemcpyDeviceToDevice, c0->stream));
+  if (n > 1) {
+    ncclResult_t r = api->GroupStart();
+    for (int i = 1; i < n && r == ncclSuccess; i++) {
+      if (!ctxs[i]->nhits) continue;
+      const size_t bytes = ctxs[i]->nhits * sizeof(musc_hit);
+      (void)hipSetDevice(ctxs[i]->device);
+      r = api->Send(ctxs[i]->hits.p, bytes, ncclUint8, 0, (*comms)[i], ctxs[i]->stream);
+      if (r != ncclSuccess) break;
+      (void)hipSetDevice(c0->device);
+      r = api->Recv(c0->gathered.p + off[i], bytes, ncclUint8, i, (*comms)[0], c0->stream);
+    }
+    const ncclResult_t r2 = api->GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return fail(c0, 20, "musc_gather_rccl: %s", api->GetErrorString(r));
+  }
+  HIPCHK(c0, hipSetDevice(c0->device));
+  for (int i = 0; i < n; i++) {
+    const uint64_t base = read_base ? read_base[i] : 0;
+    if (!base || !ctxs[i]->nhits) continue;
+    hipLaunchKernelGGL(k_rebase_reads, dim3(std::min(nblk(ctxs[i]->nhits, 256), MAX_GRID)), dim3(256), 0, c0->stream,
+                       reinterpret_cast<uint4*>(c0->gathered.p + off[i]), ctxs[i]->nhits, (uint32_t)base);
+    HIPCHK(c0, hipGetLastError());
+  }
+  for (int i = 1; i < n; i++) {  // the senders' streams
+    HIPCHK(ctxs[i], hipSetDevice(ctxs[i]->device));
+    HIPCHK(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+  }
+  HIPCHK(c0, hipSetDevice(c0->device));
+  musc_hit* h = (musc_hit*)malloc(sizeof(musc_hit) * (total ? total : 1));
+  if (!h) return fail(c0, 7, "musc_gather_rccl: out of host memory");
+  hipError_t e = hipSuccess;
+  if (total) e = hipMemcpyAsync(h, c0->gathered.p, total * sizeof(musc_hit), hipMemcpyDeviceToHost, c0->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
+  if (e != hipSuccess) {
+    free(h);
+    return fail(c0, 10, "musc_gather_rccl: %s", hipGetErrorString(e));
   }
   *hits = h;
   *nhits = total;

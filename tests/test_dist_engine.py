@@ -150,3 +150,35 @@ def test_two_rank_engine_shaped_gather_cpu(tmp_path, seed):
 @pytest.mark.parametrize("seed", [3, 14, 27])
 def test_two_rank_engines_share_one_gpu(tmp_path, seed):
     _check(tmp_path, seed, use_gpu=True)
+
+
+@pytest.mark.gpu
+def test_in_process_gather_entry_points():
+    """musc_gather / musc_gather_rccl (one process, one context per GPU -- `muscato --GPUs N`, a Go
+    host): on the one GPU of the test box the clique has a single member, so this covers the
+    packing, rebasing and copy-out paths and that both entry points agree; two contexts on one
+    device are refused by the RCCL form (it needs distinct devices) and accepted by the host form."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import make_case
+    from muscato_amd import Config, Engine, gather, sorted_hits
+    from muscato_amd.api import MuscatoError
+    ocfg, reads, targets = make_case(14)
+    cfg = Config(Windows=list(ocfg.Windows), WindowWidth=ocfg.WindowWidth, PMatch=ocfg.PMatch, MinDinuc=ocfg.MinDinuc,
+                 MaxReadLength=ocfg.MaxReadLength, MaxMatches=ocfg.MaxMatches, MMTol=ocfg.MMTol, MatchMode=ocfg.MatchMode)
+    half = len(reads) // 2
+    with Engine(0) as a, Engine(0) as b:
+        for e, part in ((a, reads[:half]), (b, reads[half:])):
+            e.load_targets(targets)
+            e.load_reads(part)
+            e.match_device(cfg, apply_mmtol=True, n_shards=2)
+        whole = gather([a, b], [0, half], rccl=False)
+        one = gather([a], [7], rccl=True)
+        ref = gather([a], [7], rccl=False)
+        assert (one == ref).all() and len(one) == a.stats()["n_hits"] and (len(one) == 0 or one[:, 0].min() >= 7)
+        with pytest.raises(MuscatoError, match="share device"):
+            gather([a, b], [0, half], rccl=True)
+    with Engine(0) as e:
+        e.load_targets(targets)
+        e.load_reads(reads)
+        exp = sorted_hits(e.match(cfg, apply_mmtol=True))
+    assert (sorted_hits(whole) == exp).all()
