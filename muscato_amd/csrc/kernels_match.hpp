@@ -373,7 +373,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   __shared__ uint32_t s_bb[NWAVE][WMAX * WT];       // bucket of (window, read), WB_NONE when the window takes no part
   __shared__ uint32_t s_oc[NWAVE][WMAX * WT];       // phase B/C: overflow entries of the probe; phase D: cnt[64], base[64]
   __shared__ uint32_t s_ovf[NWAVE][WMAX * WT];      // where in E
-  __shared__ uint32_t s_best[NWAVE][WT];
+  __shared__ uint32_t s_best[2][NWAVE][WT];  // two wave-tiles are alive at once (phase A of the next one runs before phase D)
   __shared__ uint32_t s_lcode[NWAVE][MATCH_WLIST], s_lgene[NWAVE][MATCH_WLIST], s_lpos[NWAVE][MATCH_WLIST];
   __shared__ uint32_t s_oix[NWAVE][MATCH_WOWN];  // phase C: flat item -> index within its bucket's overflow list
   __shared__ uint8_t s_own[NWAVE][MATCH_WOWN];   //          flat item -> probe (window * 64 + read)
@@ -400,6 +400,75 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   const uint32_t mmtol = (uint32_t)mp->mmtol;
   const bool apply = mp->apply_mmtol != 0;
 
+  // phase A of wave-tile wt (best-buffer `par`); returns the tile's common read length or ~0
+  auto phase_a = [&](uint32_t wt, uint32_t par) -> uint32_t {
+    const uint32_t tid = opaque(threadIdx.x);
+    const uint32_t lane = tid & 63, wid = tid >> 6;
+    uint32_t* const img_l = s_img[wid];
+    uint32_t* const bb_l = s_bb[wid];
+    uint32_t* const wcnt_l = s_dyn + wid * WT * W;
+    const uint32_t i = wt * WT + lane;
+    const bool active = i < n;
+    Rec<RW> rec;
+    rec.load(rd + (r0 + (active ? i : 0)) * (uint64_t)RW, RW);
+    const int len = (int)rec.len();
+    uint32_t valid = 0;
+    for (int k = 0; k < W; k++) {
+      uint32_t b = WB_NONE;
+      const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
+      if (active) {
+        bool pt = (uint32_t)len >= q2;
+        if (pt && mp->min_dinuc > 0)
+          pt = (ww <= 16 ? rec_count_dinuc16(rec, q1, ww) : rec_count_dinuc(rec, rec, false, q1, ww)) >= mp->min_dinuc;
+        if (pt) {
+          b = rec_bucket(rec, rec, false, q1, ww, mp->bits, mp->direct);
+          valid |= 1u << k;
+        }
+      }
+      bb_l[k * WT + lane] = b;
+      uint32_t img[8];
+      read_image<RW>(rec, 2u * (uint32_t)(CL - (int)q1), img);
+      uint4* dst = reinterpret_cast<uint4*>(&img_l[(k * WT + lane) * 8]);
+      dst[0] = make_uint4(img[0], img[1], img[2], img[3]);
+      dst[1] = make_uint4(img[4], img[5], img[6], img[7]);
+    }
+    const uint32_t budget = len < CONF_NM ? s_nm[len] : 0u;  // (reads on this path are at most 120 bases)
+    s_meta[wid][lane] = (uint32_t)len | ((budget > 127u ? 127u : budget) << 17) | (valid << 24);
+    s_best[par][wid][lane] = 0xFFFFFFFFu;
+    nvalid += __popc(valid);
+    if (block_mode)
+      for (uint32_t t = lane; t < WT * (uint32_t)W; t += 64) wcnt_l[t] = 0;
+    // every read of the wave-tile of one length: the comparisons use scalar length masks
+    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
+    return __ballot(active && (uint32_t)len != len0) == 0 ? len0 : 0xFFFFFFFFu;
+  };
+  // the bucket loads of one round of probes (16 probes, a quad each)
+  auto issue = [&](int k, int rr, uint4& a, uint4& b2) {
+    const uint32_t tid = opaque(threadIdx.x);
+    const uint32_t lane = tid & 63, wid = tid >> 6, part = lane & 3;
+    const uint32_t b = s_bb[wid][k * WT + rr * 16 + (lane >> 2)];
+    a = make_uint4(0, 0, 0, 0);
+    b2 = make_uint4(0, 0, 0, 0);
+    if (b != WB_NONE && !(dbg & 2)) {
+      const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b) + 2 * part;
+      const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
+      a = make_uint4(x.x, x.y, x.z, x.w);
+      b2 = make_uint4(y.x, y.y, y.z, y.w);
+    }
+  };
+
+  // Software pipeline over the wave's wave-tiles: phase A of the NEXT tile and the loads of its
+  // first rounds are issued before phase D of the current one, so that a wave always has bucket
+  // lines in flight (phases A..C share the per-tile LDS state; D needs only the candidate list and
+  // the tile's own best[] buffer).
+  uint4 va[MATCH_RING], vb[MATCH_RING];
+  uint32_t ulen = 0xFFFFFFFFu, par = 0;
+  if (gw < nwt) {
+    ulen = phase_a(gw, 0);
+    wave_lds_sync();
+#pragma unroll
+    for (int rr = 0; rr < MATCH_RING; rr++) issue(0, rr, va[rr], vb[rr]);
+  }
   for (uint32_t wt = gw; wt < nwt; wt += nw) {
     // (the lane's LDS addresses are derived afresh in every iteration: kept across the loop they
     // would occupy dozens of registers and spill)
@@ -412,45 +481,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
     uint32_t* const cnt_l = s_oc[wid];
     uint32_t* const base_l = s_oc[wid] + WT;
     uint32_t* const wcnt_l = s_dyn + wid * WT * W;
-    // ---- phase A
-    uint32_t ulen;  // the common read length of the wave-tile, or ~0 (wave-uniform)
-    {
-      const uint32_t i = wt * WT + lane;
-      const bool active = i < n;
-      Rec<RW> rec;
-      rec.load(rd + (r0 + (active ? i : 0)) * (uint64_t)RW, RW);
-      const int len = (int)rec.len();
-      uint32_t valid = 0;
-      for (int k = 0; k < W; k++) {
-        uint32_t b = WB_NONE;
-        const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
-        if (active) {
-          bool pt = (uint32_t)len >= q2;
-          if (pt && mp->min_dinuc > 0)
-            pt = (ww <= 16 ? rec_count_dinuc16(rec, q1, ww) : rec_count_dinuc(rec, rec, false, q1, ww)) >= mp->min_dinuc;
-          if (pt) {
-            b = rec_bucket(rec, rec, false, q1, ww, mp->bits, mp->direct);
-            valid |= 1u << k;
-          }
-        }
-        bb_l[k * WT + lane] = b;
-        uint32_t img[8];
-        read_image<RW>(rec, 2u * (uint32_t)(CL - (int)q1), img);
-        uint4* dst = reinterpret_cast<uint4*>(&img_l[(k * WT + lane) * 8]);
-        dst[0] = make_uint4(img[0], img[1], img[2], img[3]);
-        dst[1] = make_uint4(img[4], img[5], img[6], img[7]);
-      }
-      const uint32_t budget = len < CONF_NM ? s_nm[len] : 0u;  // (reads on this path are at most 120 bases)
-      s_meta[wid][lane] = (uint32_t)len | ((budget > 127u ? 127u : budget) << 17) | (valid << 24);
-      s_best[wid][lane] = 0xFFFFFFFFu;
-      nvalid += __popc(valid);
-      if (block_mode)
-        for (uint32_t t = lane; t < WT * (uint32_t)W; t += 64) wcnt_l[t] = 0;
-      // every read of the wave-tile of one length: the comparisons use scalar length masks
-      const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
-      ulen = __ballot(active && (uint32_t)len != len0) == 0 ? len0 : 0xFFFFFFFFu;
-    }
-    wave_lds_sync();
+    uint32_t* const best_l = s_best[par][wid];
     uint32_t nlist = 0;  // reported candidates of this wave-tile so far (wave-uniform)
 
     // one reported candidate per set lane of the vote, appended in lane order
@@ -464,7 +495,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       const uint32_t slot = nlist + below;
       nlist += (uint32_t)__popcll(vote);
       if (!rep) return;
-      atomicMin(&s_best[wid][w >> 24], w & 0xFFFFu);
+      atomicMin(&best_l[w >> 24], w & 0xFFFFu);
       nrep++;
       if (slot < MATCH_WLIST) {
         s_lcode[wid][slot] = w;
@@ -498,17 +529,6 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
     };
 
     // ---- phase B
-    auto issue = [&](int k, int rr, uint4& a, uint4& b2) {
-      const uint32_t b = bb_l[k * WT + rr * 16 + (lane >> 2)];
-      a = make_uint4(0, 0, 0, 0);
-      b2 = make_uint4(0, 0, 0, 0);
-      if (b != WB_NONE && !(dbg & 2)) {
-        const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b) + 2 * part;
-        const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
-        a = make_uint4(x.x, x.y, x.z, x.w);
-        b2 = make_uint4(y.x, y.y, y.z, y.w);
-      }
-    };
     auto process = [&](auto ulen_tag, int k, int q1, uint32_t sh, int rr, const uint4& a, const uint4& b2) {
       // (opaque: the probes of round rr belong to the same reads for every window; the compiler
       // would otherwise keep what it derives from them in registers across the window loop)
@@ -534,9 +554,6 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
     {
       // a ring of four register buffers over the W x 4 rounds: a round's registers are refilled
       // with the same round of the next window as soon as it has been used
-      uint4 va[MATCH_RING], vb[MATCH_RING];
-#pragma unroll
-      for (int rr = 0; rr < MATCH_RING; rr++) issue(0, rr, va[rr], vb[rr]);
       auto rounds = [&](auto ulen_tag) {
 #pragma unroll 1
         for (int k = 0; k < W; k++) {
@@ -641,8 +658,16 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
           else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
         }
       }
-      wave_lds_sync();  // phase C is done with s_oc: it becomes cnt / base
-      cnt_l[lane] = 0;
+      wave_lds_sync();  // phases A..C of this tile are done with the per-tile LDS state
+      // the next wave-tile: phase A and the loads of its first rounds, in flight during phase D
+      uint32_t ulen_next = 0xFFFFFFFFu;
+      if (wt + nw < nwt) {
+        ulen_next = phase_a(wt + nw, par ^ 1u);
+        wave_lds_sync();
+#pragma unroll
+        for (int rr = 0; rr < MATCH_RING; rr++) issue(0, rr, va[rr], vb[rr]);
+      }
+      cnt_l[lane] = 0;  // s_oc becomes cnt / base
       wave_lds_sync();
       auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) -> uint32_t {
         if (j < MATCH_WLIST) {
@@ -661,7 +686,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
         uint32_t g, p;
         const uint32_t w = item(j, &g, &p);
         const uint32_t rl = w >> 24;
-        const uint32_t thr = apply ? s_best[wid][rl] + mmtol : 0xFFFFu;
+        const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
         if ((w & 0xFFFFu) <= thr) atomicAdd(&cnt_l[rl], 1u);
       }
       wave_lds_sync();
@@ -682,14 +707,16 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
           uint32_t g, p;
           const uint32_t w = item(j, &g, &p);
           const uint32_t rl = w >> 24, v = w & 0xFFFFu;
-          const uint32_t thr = apply ? s_best[wid][rl] + mmtol : 0xFFFFu;
+          const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
           if (v > thr) continue;
           const uint32_t ord = atomicAdd(&cnt_l[rl], 1u);
           stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt * WT + rl), g, p, v);
         }
       }
       used += total;
-      wave_lds_sync();  // the next wave-tile rewrites the LDS state
+      ulen = ulen_next;
+      par ^= 1u;
+      wave_lds_sync();  // the next wave-tile's phase B rewrites s_oc / the candidate list
     }
   }
   // One reduction per workgroup and a handful of atomics from its first thread: atomics on one
