@@ -1,0 +1,24 @@
+#!/bin/bash
+# The committed bench lines of a round (run from the repo root through gpurun):
+#   profiles/bench_lines.sh r02
+tag=${1:-r02}
+o=gpurun_out
+python bench.py --steps 20 --warmup 5 > $o/${tag}_cfg3_bench.json 2> $o/${tag}_cfg3_bench.err || echo "cfg3 FAILED"
+python bench.py --steps 20 --warmup 5 --index classic --no-cpu-baseline --no-survey-scope > $o/${tag}_cfg3_classic_bench.json 2>/dev/null || echo "cfg3 classic FAILED"
+python bench.py --workload cfg2 --steps 50 --warmup 5 > $o/${tag}_cfg2_bench.json 2>/dev/null || echo "cfg2 FAILED"
+python bench.py --workload cfg4shard --steps 20 --warmup 5 --no-cpu-baseline > $o/${tag}_cfg4shard_bench.json 2>/dev/null || echo "cfg4shard FAILED"
+python bench.py --workload cfg5shard --steps 10 --warmup 3 --no-cpu-baseline > $o/${tag}_cfg5shard_bench.json 2>/dev/null || echo "cfg5shard FAILED"
+# two ranks on ONE GPU over gloo (RCCL refuses two ranks on one device): the N>1 control flow only
+MUSC_BENCH_BACKEND=gloo MUSC_BENCH_DEVICE=0 MUSC_INDEX=classic timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+  --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 1 --reads 5000000 > $o/${tag}_n2_rehearsal.json 2> $o/${tag}_n2_rehearsal.err || { echo "n2 FAILED"; tail -5 $o/${tag}_n2_rehearsal.err; }
+for f in cfg3 cfg3_classic cfg2 cfg4shard cfg5shard n2_rehearsal; do
+  python - <<PY
+import json
+try:
+    d = json.loads([l for l in open("$o/${tag}_${f}_bench.json" if "$f" != "n2_rehearsal" else "$o/${tag}_n2_rehearsal.json") if l.startswith("{")][-1])
+    r = d["roofline"]
+    print("%-14s %-48s ms/step %.3f  value %.3g  kernel %s frac %.3f  hits %d" % ("$f", d["config"]["workload"][:48], d["ms_per_step"], d["value"] or 0, r["kernel"][:9], r["frac"], d["per_step"]["hits"]))
+except Exception as e:
+    print("$f", "unreadable", e)
+PY
+done

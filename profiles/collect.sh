@@ -36,5 +36,5 @@ f=$(find $out/marker -name "*marker_api_stats.csv" -o -name "*marker*stats.csv" 
 [ -n "$f" ] && cp "$f" gpurun_out/${tag}_cfg3_marker_stats.csv
 python3 profiles/pmc_summary.py $out > gpurun_out/${tag}_cfg3_pmc_summary.txt
 python3 profiles/traffic_from_pmc.py $out cfg3 k_match k_screen k_confirm k_compact > gpurun_out/${tag}_traffic.json
-cat gpurun_out/${tag}_cfg3_auto_kernel_stats.csv | head -8
+rm -rf $out/pmc_* $out/stats_*/*/*.db 2>/dev/null; du -sh $out; cat gpurun_out/${tag}_cfg3_auto_kernel_stats.csv | head -8
 cat gpurun_out/${tag}_traffic.json | head -60
