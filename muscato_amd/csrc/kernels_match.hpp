@@ -374,7 +374,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   __shared__ uint32_t s_oc[NWAVE][WMAX * WT];       // phase B/C: overflow entries of the probe; phase D: cnt[64], base[64]
   __shared__ uint32_t s_ovf[NWAVE][WMAX * WT];      // where in E
   __shared__ uint32_t s_best[2][NWAVE][WT];  // two wave-tiles are alive at once (phase A of the next one runs before phase D)
-  __shared__ uint32_t s_lcode[NWAVE][MATCH_WLIST], s_lgene[NWAVE][MATCH_WLIST], s_lpos[NWAVE][MATCH_WLIST];
+  __shared__ uint3 s_list[NWAVE][MATCH_WLIST];  // reported candidates: result word, gene, position
   __shared__ uint32_t s_oix[NWAVE][MATCH_WOWN];  // phase C: flat item -> index within its bucket's overflow list
   __shared__ uint8_t s_own[NWAVE][MATCH_WOWN];   //          flat item -> probe (window * 64 + read)
   __shared__ uint16_t s_nm[CONF_NM];
@@ -496,11 +496,8 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       nlist += (uint32_t)__popcll(vote);
       if (!rep) return;
       atomicMin(&best_l[w >> 24], w & 0xFFFFu);
-      nrep++;
       if (slot < MATCH_WLIST) {
-        s_lcode[wid][slot] = w;
-        s_lgene[wid][slot] = gene;
-        s_lpos[wid][slot] = pos;
+        s_list[wid][slot] = make_uint3(w, gene, pos);
       } else if (slot - MATCH_WLIST < sregion) {
         spill[sregion0 + (slot - MATCH_WLIST)] = make_uint4(w, gene, pos, 0u);
       }
@@ -515,8 +512,11 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       uint32_t z = 0;
       const bool ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, rlen, &z);
       uint32_t w = NX_REJECT;
+      {
+        const unsigned long long okv = __ballot(ok);  // counted by the scalar unit, credited to one lane
+        ncmp += lane == 0 ? (uint32_t)__popcll(okv) : 0u;
+      }
       if (ok) {
-        ncmp++;
         uint32_t img[8];
         const uint4* src = reinterpret_cast<const uint4*>(&img_l[(k * WT + ri) * 8]);
         const uint4 i0 = src[0], i1 = src[1];
@@ -671,9 +671,10 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       wave_lds_sync();
       auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) -> uint32_t {
         if (j < MATCH_WLIST) {
-          *gene = s_lgene[wid][j];
-          *pos = s_lpos[wid][j];
-          return s_lcode[wid][j];
+          const uint3 it = s_list[wid][j];
+          *gene = it.y;
+          *pos = it.z;
+          return it.x;
         }
         // written by other lanes of this wave a moment ago: read past the L1
         const uint32_t* sp = reinterpret_cast<const uint32_t*>(spill + sregion0 + (j - MATCH_WLIST));
@@ -714,6 +715,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
         }
       }
       used += total;
+      nrep += lane == 0 ? nl : 0u;  // (one lane carries the wave-uniform count into the final reduction)
       ulen = ulen_next;
       par ^= 1u;
       wave_lds_sync();  // the next wave-tile's phase B rewrites s_oc / the candidate list
