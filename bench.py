@@ -345,8 +345,31 @@ def main() -> int:
         pack_bits = [max(1, (total_loaded - 1).bit_length()), max(1, (wl.n_targets - 1).bit_length()),
                      max(1, wl.target_len.bit_length()), max(1, budget.bit_length())]
         use_packed = sum(pack_bits) <= 64 and not os.environ.get("MUSC_BENCH_UNPACKED")
-        gatherer = HitGatherer(HitGatherer.agree_capacity(n0, gdev), gdev, packed=use_packed)
+        # the compact form when gene | pos | nmiss fit one u32 word: the read index rides as one count
+        # byte per read (the list is read-major) -- 5.2 bytes per tuple at cfg4 against 8
+        use_compact = sum(pack_bits[1:]) <= 32 and use_packed and not os.environ.get("MUSC_BENCH_NO_COMPACT")
+        cap = HitGatherer.agree_capacity(n0, gdev)
+        if use_compact:
+            # every rank must be able to use the form (no read with more than 255 tuples, fields fit):
+            # tried once on the pass that sized the buffers, agreed over all ranks
+            ok = 1
+            try:
+                tw = torch.empty(max(n0, 1), dtype=torch.int32, device=device)
+                tc = torch.empty(max(n_loaded, 4), dtype=torch.uint8, device=device)
+                eng.hits_to_compact(tw.data_ptr(), max(n0, 1), tc.data_ptr(), max(n_loaded, 4), True, pack_bits[1:])
+                del tw, tc
+            except Exception as e:
+                log("compact tuples not usable on this rank (%r): 8-byte form" % (e,))
+                ok = 0
+            okt = torch.tensor([ok], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            use_compact = bool(int(okt.item()))
+        if use_compact:
+            gatherer = HitGatherer(cap, gdev, compact_reads=max(loaded))
+        else:
+            gatherer = HitGatherer(cap, gdev, packed=use_packed)
         gather_mode = "overlapped (HitGatherer, grouped send/recv), " + (
+            "compact tuples: u32 word %s + one count byte per read" % pack_bits[1:] if use_compact else
             "8-byte packed tuples %s" % pack_bits if use_packed else "16-byte tuples")
 
     overflow_seen = [0]
@@ -356,6 +379,11 @@ def main() -> int:
         overflow_seen[0] = max(overflow_seen[0], eng.stats()["n_overflow_blocks"])
         if gatherer is not None:
             def fill(buf):
+                if gatherer.compact_reads:
+                    counts, words = gatherer.compact_views(buf)
+                    eng.hits_to_compact(words.data_ptr(), gatherer.cap, counts.data_ptr(), gatherer.compact_reads,
+                                        buf.is_cuda, pack_bits[1:])
+                    return n, n_loaded
                 if n and gatherer.packed:
                     eng.hits_to_packed(buf.data_ptr(), n, buf.is_cuda, pack_bits, read_base)
                 elif n:

@@ -199,6 +199,14 @@ int musc_hits_copy_packed(musc_ctx* ctx, uint64_t* dst, uint64_t capacity, int d
                           uint64_t read_base, const int32_t* bits);
 int musc_hits_unpack(musc_ctx* ctx, const uint64_t* src, uint64_t n, int on_device, const int32_t* bits,
                      musc_hit* dst);
+/* The most compact wire form (5 bytes per tuple at one tuple per read, against 8 and 16): the hit
+ * list is read-major -- a read's tuples are contiguous and reads come in increasing order -- so the
+ * read index travels as counts[r] = number of tuples of read r (one byte per loaded read) and a
+ * tuple is one u32 word gene | pos | nmiss with bits[3] = the widths of gene, pos, nmiss (sum <= 32).
+ * Fails with code 8 if a field does not fit or a read has more than 255 tuples (use the 8-byte
+ * form then).  words: room for nhits words, counts: room for the loaded reads. */
+int musc_hits_copy_compact(musc_ctx* ctx, uint32_t* words, uint64_t words_capacity, uint8_t* counts,
+                           uint64_t counts_capacity, int dst_on_device, const int32_t* bits);
 int musc_match(musc_ctx* ctx, const musc_params* params, musc_hit** hits, uint64_t* nhits);
 void musc_free_hits(musc_hit* hits);
 

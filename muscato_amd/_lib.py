@@ -57,7 +57,7 @@ SYMBOLS = [
     "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error",
     "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for",
     "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique",
-    "musc_match_device", "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_unpack", "musc_match", "musc_free_hits",
+    "musc_match_device", "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_free_hits",
     "musc_get_stats", "musc_gather", "musc_gather_rccl", "musc_overflow_probes", "musc_free_u32",
 ]
 
@@ -95,6 +95,7 @@ def load() -> ctypes.CDLL:
     lib.musc_match_device.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(u64)]
     lib.musc_hits_copy.argtypes = [vp, vp, u64, ctypes.c_int]
     lib.musc_hits_copy_packed.argtypes = [vp, vp, u64, ctypes.c_int, u64, ctypes.POINTER(i32)]
+    lib.musc_hits_copy_compact.argtypes = [vp, vp, u64, vp, u64, ctypes.c_int, ctypes.POINTER(i32)]
     lib.musc_hits_unpack.argtypes = [vp, vp, u64, ctypes.c_int, ctypes.POINTER(i32), vp]
     lib.musc_match.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.musc_free_hits.argtypes = [vp]
@@ -109,7 +110,7 @@ def load() -> ctypes.CDLL:
     lib.musc_gather_rccl.argtypes = lib.musc_gather.argtypes
     for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for", "musc_db_build_index_for",
                  "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique", "musc_match_device",
-                 "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_unpack", "musc_match", "musc_get_stats",
+                 "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_get_stats",
                  "musc_gather", "musc_gather_rccl"):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib

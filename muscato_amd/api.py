@@ -281,6 +281,14 @@ class Engine:
         self._check(self._lib.musc_hits_copy_packed(self._h, ptr, capacity, 1 if on_device else 0, read_base, b),
                     "musc_hits_copy_packed")
 
+    def hits_to_compact(self, words_ptr: int, words_cap: int, counts_ptr: int, counts_cap: int, on_device: bool,
+                        bits: Sequence[int]) -> None:
+        """The last pass's tuples as one u32 word each (gene | pos | nmiss, widths `bits`) plus one
+        byte per loaded read = its number of tuples (musc_hits_copy_compact: the list is read-major)."""
+        b = (ctypes.c_int32 * 3)(*bits)
+        self._check(self._lib.musc_hits_copy_compact(self._h, words_ptr, words_cap, counts_ptr, counts_cap,
+                                                     1 if on_device else 0, b), "musc_hits_copy_compact")
+
     def unpack_hits(self, src_ptr: int, n: int, on_device: bool, bits: Sequence[int], dst_ptr: int) -> None:
         b = (ctypes.c_int32 * 4)(*bits)
         self._check(self._lib.musc_hits_unpack(self._h, src_ptr, n, 1 if on_device else 0, b, dst_ptr), "musc_hits_unpack")

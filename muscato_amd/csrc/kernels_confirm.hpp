@@ -431,3 +431,26 @@ __global__ __launch_bounds__(256) void k_unpack_hits(const uint64_t* __restrict_
     hits[i] = make_uint4((uint32_t)v, gene, pos, nm);
   }
 }
+
+// Tuples in their most compact wire form.  The hit list is read-major (a read's tuples are
+// contiguous, reads in increasing order: both match paths stage them that way), so the read index
+// travels as one byte per read -- counts[r] = tuples of read r -- and a tuple is ONE u32 word:
+// gene | pos | nmiss with caller-chosen widths.  *bad: 1 a field does not fit, 2 a read has more
+// than 255 tuples, 4 the list is not read-major (cannot happen; checked because the format rests on it).
+__global__ __launch_bounds__(256) void k_pack_compact(const uint4* __restrict__ hits, uint64_t n, PackBits b,
+                                                      uint32_t* __restrict__ words, uint8_t* __restrict__ counts,
+                                                      uint32_t* __restrict__ bad) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 h = hits[i];
+    if (((uint64_t)h.y >> b.gene) || ((uint64_t)h.z >> b.pos) || ((uint64_t)h.w >> b.nmiss)) atomicOr(bad, 1u);
+    words[i] = (((h.y << b.pos) | h.z) << b.nmiss) | h.w;
+    const uint32_t prev = i ? hits[i - 1].x : 0xFFFFFFFFu;
+    if (i && prev > h.x) atomicOr(bad, 4u);
+    if (i == 0 || prev != h.x) {  // the first tuple of its read counts the run
+      uint32_t cnt = 1;
+      while (i + cnt < n && cnt < 256 && hits[i + cnt].x == h.x) cnt++;
+      if (cnt > 255) atomicOr(bad, 2u);
+      counts[h.x] = (uint8_t)cnt;
+    }
+  }
+}

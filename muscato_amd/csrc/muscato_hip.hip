@@ -1533,6 +1533,51 @@ int musc_hits_copy_packed(musc_ctx* c, uint64_t* dst, uint64_t capacity, int dst
   return 0;
 }
 
+int musc_hits_copy_compact(musc_ctx* c, uint32_t* words, uint64_t words_cap, uint8_t* counts, uint64_t counts_cap,
+                           int dst_on_device, const int32_t* bits) {
+  if (!c) return 1;
+  if (!bits) return fail(c, 2, "bits is NULL");
+  int sum = 0;
+  for (int i = 0; i < 3; i++) {
+    if (bits[i] < 1 || bits[i] > 30) return fail(c, 2, "field width %d outside 1..30", bits[i]);
+    sum += bits[i];
+  }
+  if (sum > 32) return fail(c, 2, "field widths add up to %d > 32 bits", sum);
+  if (words_cap < c->nhits) return fail(c, 2, "musc_hits_copy_compact: room for %llu tuples < %llu",
+                                        (unsigned long long)words_cap, (unsigned long long)c->nhits);
+  if (counts_cap < c->nreads) return fail(c, 2, "musc_hits_copy_compact: room for %llu reads < %llu",
+                                          (unsigned long long)counts_cap, (unsigned long long)c->nreads);
+  if ((c->nhits && !words) || (c->nreads && !counts)) return fail(c, 2, "musc_hits_copy_compact: NULL destination");
+  HIPCHK(c, hipSetDevice(c->device));
+  const PackBits b{0, bits[0], bits[1], bits[2]};
+  uint32_t* dw = words;
+  uint8_t* dc = counts;
+  if (!dst_on_device) {  // stage on the device, then one copy each
+    int rc = ensure(c, c->packed, (c->nhits * 4 + c->nreads + 15) / 8 + 2);
+    if (rc) return rc;
+    dw = reinterpret_cast<uint32_t*>(c->packed.p);
+    dc = reinterpret_cast<uint8_t*>(dw + c->nhits);
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+  if (c->nreads) HIPCHK(c, hipMemsetAsync(dc, 0, c->nreads, c->stream));
+  if (c->nhits) {
+    hipLaunchKernelGGL(k_pack_compact, dim3(std::min(nblk(c->nhits, 256), MAX_GRID)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint4*>(c->hits.p), c->nhits, b, dw, dc, c->d_flag);
+    HIPCHK(c, hipGetLastError());
+  }
+  uint32_t bad = 0;
+  HIPCHK(c, hipMemcpyAsync(&bad, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+  if (!dst_on_device) {
+    if (c->nhits) HIPCHK(c, hipMemcpyAsync(words, dw, c->nhits * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->nreads) HIPCHK(c, hipMemcpyAsync(counts, dc, c->nreads, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (bad & 4u) return fail(c, 12, "internal: the hit list is not read-major");
+  if (bad) return fail(c, 8, "musc_hits_copy_compact: %s", (bad & 1u) ? "a tuple field does not fit its width"
+                                                                      : "a read has more than 255 tuples");
+  return 0;
+}
+
 int musc_hits_unpack(musc_ctx* c, const uint64_t* src, uint64_t n, int on_device, const int32_t* bits, musc_hit* dst) {
   if (!c) return 1;
   PackBits b;

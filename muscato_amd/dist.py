@@ -72,11 +72,21 @@ class HitGatherer:
     everything; on `dst`, counts(k) / last_result() then give the tuples per rank -- rank-order
     concatenation is the global read order."""
 
-    def __init__(self, cap: int, device, depth: int = 2, dst: int = 0, group=None, packed: bool = False):
+    def __init__(self, cap: int, device, depth: int = 2, dst: int = 0, group=None, packed: bool = False,
+                 compact_reads: int = 0):
+        """compact_reads > 0 selects the compact form (musc_hits_copy_compact; `compact_reads` = the
+        largest number of reads any rank holds): a buffer is int32 words [n tuples, n reads] +
+        one count byte per read + one word per tuple -- 5 bytes per tuple at one tuple per read,
+        against 8 (packed) and 16.  fill(buf) then writes through compact_views(buf) and returns
+        (n, n_reads)."""
         self.cap, self.depth, self.dst, self.group, self.packed = int(cap), depth, dst, group, packed
+        self.compact_reads = int(compact_reads)
+        self.cw = (self.compact_reads + 3) // 4  # words of the count bytes
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         shape, dtype = ((self.cap + 1,), torch.int64) if packed else ((self.cap + 1, 4), torch.int32)
+        if self.compact_reads:
+            shape, dtype = (2 + self.cw + self.cap,), torch.int32
         self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self.recv = None
         if self.rank == dst:
@@ -103,10 +113,19 @@ class HitGatherer:
         k = self.i % self.depth
         self._wait(k)
         buf = self.send[k]
-        n = int(fill(buf))
+        n = fill(buf)
+        nreads = 0
+        if self.compact_reads:
+            n, nreads = n
+            if nreads > self.compact_reads:
+                raise RuntimeError("HitGatherer: %d reads exceed the agreed capacity %d" % (nreads, self.compact_reads))
+        n = int(n)
         if n > self.cap:
             raise RuntimeError("HitGatherer: %d hits exceed the agreed capacity %d" % (n, self.cap))
-        if self.packed:
+        if self.compact_reads:
+            buf[0] = n
+            buf[1] = int(nreads)
+        elif self.packed:
             buf[self.cap] = n
         else:
             if read_base and n:
@@ -123,8 +142,26 @@ class HitGatherer:
 
     def counts(self, k: int) -> List[int]:
         """Tuple counts per rank of buffer set k (rank dst, after its transfers completed)."""
-        last = self.recv[k][:, self.cap] if self.packed else self.recv[k][:, self.cap, 0]
+        if self.compact_reads:
+            last = self.recv[k][:, 0]
+        else:
+            last = self.recv[k][:, self.cap] if self.packed else self.recv[k][:, self.cap, 0]
         return [int(c) for c in last.tolist()]
+
+    def compact_views(self, buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(count bytes [compact_reads] uint8, tuple words [cap] int32) of a compact buffer."""
+        counts = buf[2:2 + self.cw].view(torch.uint8)[:self.compact_reads]
+        return counts, buf[2 + self.cw:]
+
+    def unpack_compact(self, slab: torch.Tensor, read_base: int, bits) -> torch.Tensor:
+        """One rank's compact buffer -> int64 [n, 4] (read + read_base, gene, pos, nmiss)."""
+        n, nreads = int(slab[0]), int(slab[1])
+        counts, words = self.compact_views(slab)
+        bg, bp, bn = bits
+        reads = torch.repeat_interleave(torch.arange(nreads, device=slab.device, dtype=torch.int64) + int(read_base),
+                                        counts[:nreads].to(torch.int64))
+        w = words[:n].to(torch.int64) & 0xFFFFFFFF
+        return torch.stack([reads, (w >> (bp + bn)) & ((1 << bg) - 1), (w >> bn) & ((1 << bp) - 1), w & ((1 << bn) - 1)], dim=1)
 
     def finish(self) -> Optional[List[int]]:
         """Wait for all outstanding transfers; on dst return the per-rank counts of the last pass."""
@@ -153,4 +190,12 @@ class HitGatherer:
         if self.rank != self.dst or self.i == 0:
             return None
         k = (self.i - 1) % self.depth
+        if self.compact_reads:
+            raise RuntimeError("compact buffers carry no read numbers: use last_slabs() + unpack_compact()")
         return torch.cat([self.recv[k][r][:c] for r, c in enumerate(self.counts(k))], dim=0)
+
+    def last_slabs(self) -> Optional[torch.Tensor]:
+        """After finish(): rank dst's receive buffer of the last pass, one slab per rank."""
+        if self.rank != self.dst or self.i == 0:
+            return None
+        return self.recv[(self.i - 1) % self.depth]

@@ -18,6 +18,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BITS = (16, 12, 16, 8)
+CBITS = (12, 14, 6)  # gene, pos, nmiss of the compact form: 32 bits
 
 
 def _free_port():
@@ -61,6 +62,16 @@ class OracleEngine:
              << np.uint64(bits[3])) | h[:, 3]
         w = np.ascontiguousarray(w)
         ctypes.memmove(ptr, w.ctypes.data, w.nbytes)
+
+    def hits_to_compact(self, words_ptr, words_cap, counts_ptr, counts_cap, on_device, bits):
+        import ctypes
+        h = self.hits.astype(np.uint64)
+        assert words_cap >= len(h) and counts_cap >= self.n_reads and not on_device
+        w = (((h[:, 1] << np.uint64(bits[1])) | h[:, 2]) << np.uint64(bits[2]) | h[:, 3]).astype(np.uint32)
+        cnt = np.bincount(self.hits[:, 0].astype(np.int64), minlength=self.n_reads).astype(np.uint8)
+        w = np.ascontiguousarray(w)
+        ctypes.memmove(words_ptr, w.ctypes.data, w.nbytes)
+        ctypes.memmove(counts_ptr, cnt.ctypes.data, cnt.nbytes)
 
     def stats(self):
         return {"n_overflow_blocks": 0}
@@ -114,7 +125,25 @@ def _worker(rank, world, port, seed, outdir, use_gpu):
             res = g.last_result()
             out["packed" if packed else "plain"] = (cn, HitGatherer.unpack(res, BITS) if packed else res.to(torch.int64),
                                                     int(o.item()))
+    # the compact form: one count byte per read + one u32 word per tuple
+    nmax = torch.tensor([eng.n_reads], dtype=torch.int64)
+    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+    g = HitGatherer(HitGatherer.agree_capacity(n0, dev), dev, depth=2, compact_reads=int(nmax.item()))
+    for _ in range(3):
+        n = eng.match_device(cfg, apply_mmtol=True, n_shards=world)
+
+        def fillc(buf, n=n):
+            counts, words = g.compact_views(buf)
+            eng.hits_to_compact(words.data_ptr(), g.cap, counts.data_ptr(), g.compact_reads, False, CBITS)
+            return n, eng.n_reads
+        g.submit(fillc, lo)
+    cn = g.finish()
+    bases = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(bases, torch.tensor([lo], dtype=torch.int64))
     if rank == 0:
+        slabs = g.last_slabs()
+        res = torch.cat([g.unpack_compact(slabs[r], int(bases[r]), CBITS) for r in range(world)], dim=0)
+        out["compact"] = (cn, res, 0)
         torch.save(out, os.path.join(outdir, "out.pt"))
     if not use_gpu:
         assert eng.n_shards_seen and all(s == world for s in eng.n_shards_seen)
@@ -132,7 +161,7 @@ def _check(tmp_path, seed, use_gpu):
     ocfg, reads, targets = make_case(seed)
     exp = sorted(orc.best_filter(orc.match_direct(reads, targets, ocfg), ocfg.MMTol))
     exp = torch.tensor(exp, dtype=torch.int64).reshape(-1, 4)
-    for form in ("plain", "packed"):
+    for form in ("plain", "packed", "compact"):
         cn, res, overflow = out[form]
         assert overflow == 0 and sum(cn) == len(exp)
         # per-shard tuples come out read-major; order within a read is unspecified

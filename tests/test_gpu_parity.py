@@ -298,6 +298,55 @@ def test_packed_tuples_roundtrip(eng):
         eng.hits_to_packed(words.ctypes.data, n, False, [32, 32, 32, 8])
 
 
+def test_compact_tuples(eng):
+    """musc_hits_copy_compact: one u32 word per tuple + one count byte per read (the hit list is
+    read-major), to host and to device memory; loud failures when a field does not fit, when the
+    widths exceed 32 bits, and when a read has more than 255 tuples."""
+    import ctypes
+    ocfg, reads, targets = make_case(77)
+    exp = gpu_hits(eng, ocfg, reads, targets, False)
+    n, nr = len(exp), len(reads)
+    bits = [max(1, len(targets).bit_length()), max(1, max(len(t) for t in targets).bit_length()), 8]
+    assert sum(bits) <= 32
+    words = np.zeros(n, dtype=np.uint32)
+    counts = np.full(nr, 77, dtype=np.uint8)
+    eng.hits_to_compact(words.ctypes.data, n, counts.ctypes.data, nr, False, bits)
+    assert int(counts.sum()) == n and (counts == np.bincount(exp[:, 0], minlength=nr)).all()
+    rd = np.repeat(np.arange(nr, dtype=np.uint32), counts)
+    w = words.astype(np.uint64)
+    back = np.stack([rd, (w >> np.uint64(bits[1] + bits[2])).astype(np.uint32),
+                     ((w >> np.uint64(bits[2])) & np.uint64((1 << bits[1]) - 1)).astype(np.uint32),
+                     (w & np.uint64((1 << bits[2]) - 1)).astype(np.uint32)], axis=1)
+    from muscato_amd import sorted_hits
+    assert (sorted_hits(back) == exp).all()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    dw, dc = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dw), n * 4 + 16) == 0 and hip.hipMalloc(ctypes.byref(dc), nr + 16) == 0
+    try:
+        eng.hits_to_compact(dw.value, n, dc.value, nr, True, bits)
+        w2, c2 = np.zeros(n, dtype=np.uint32), np.zeros(nr, dtype=np.uint8)
+        assert hip.hipMemcpy(w2.ctypes.data, dw, n * 4, 2) == 0 and hip.hipMemcpy(c2.ctypes.data, dc, nr, 2) == 0
+        assert (w2 == words).all() and (c2 == counts).all()
+    finally:
+        hip.hipFree(dw)
+        hip.hipFree(dc)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        eng.hits_to_compact(words.ctypes.data, n, counts.ctypes.data, nr, False, [bits[0], 1, 8])
+    with pytest.raises(RuntimeError, match="32 bits"):
+        eng.hits_to_compact(words.ctypes.data, n, counts.ctypes.data, nr, False, [20, 10, 8])
+    # one read matching 300 targets: more tuples than a count byte holds
+    tg = [b"ACGTACGTAGGATCCATTGA" + rand_seq(random.Random(i), 12, b"ACGT") for i in range(300)]
+    c = orc.Config(Windows=[0], WindowWidth=10, PMatch=1.0, MaxReadLength=20, MaxMatches=100000)
+    got = gpu_hits(eng, c, [b"ACGTACGTAGGATCCATTGA"], tg, False)
+    assert len(got) == 300
+    w3, c3 = np.zeros(300, dtype=np.uint32), np.zeros(1, dtype=np.uint8)
+    with pytest.raises(RuntimeError, match="255 tuples"):
+        eng.hits_to_compact(w3.ctypes.data, 300, c3.ctypes.data, 1, False, [12, 8, 4])
+
+
 def test_sixteen_windows(eng):
     """The maximum number of windows (eight chunks of two in k_screen, a 16 KB window-counter
     block in k_confirm), overlapping and at odd offsets, with a tight MaxMatches check."""
