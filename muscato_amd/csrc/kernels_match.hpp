@@ -252,20 +252,20 @@ DEV void read_image(const Rec<RW>& rec, uint32_t sh, uint32_t (&img)[8]) {
 //   ULEN   : every read of the wave-tile has the same length `len` (wave-uniform) -- the masks are
 //            rows of the host's tables then, read by the scalar unit; otherwise the length mask is
 //            per lane arithmetic
+//   lm     : ULEN: the row mp->lm[len][k], loaded by the caller once per window (eight scalars)
 template <bool ULEN>
 DEV uint32_t ctx_score(const uint32_t (&img)[8], const uint32_t (&c)[8], uint32_t sh, uint32_t k,
                        const MatchParams* __restrict__ mp, int W, uint32_t exact0, uint32_t budget, uint32_t slot,
-                       uint32_t len) {
+                       uint32_t len, const uint32_t (&lm)[8]) {
   uint32_t d[8];
   uint32_t nx = 0;
-  // (readfirstlane: tells the compiler the index is wave-uniform, so the row is read by scalar loads)
-  const uint32_t* __restrict__ lmrow = mp->lm[ULEN ? __builtin_amdgcn_readfirstlane((int)len) : 0][__builtin_amdgcn_readfirstlane((int)k)];
+  // (readfirstlane: tells the compiler the index is wave-uniform, so the rows are read by scalar loads)
   const uint32_t ku = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const uint32_t x = img[j] ^ c[j];
     uint32_t m;
-    if constexpr (ULEN) m = lmrow[j];
+    if constexpr (ULEN) m = lm[j];
     else m = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
     d[j] = (x | (x >> 1)) & m;
     nx += __popc(d[j]);
@@ -504,8 +504,8 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
     };
 
     // one entry (context words c, c[7] still carrying rem16 in its high half) of probe (k, ri)
-    auto compare = [&](auto ulen_tag, uint32_t k, int q1, uint32_t sh, uint32_t ri, uint32_t jx, bool live,
-                       uint32_t (&c)[8]) -> uint32_t {
+    auto compare = [&](auto ulen_tag, uint32_t k, int q1, uint32_t sh, const uint32_t (&lm)[8], uint32_t ri, uint32_t jx,
+                       bool live, uint32_t (&c)[8]) -> uint32_t {
       constexpr bool ULEN = decltype(ulen_tag)::value;
       const uint32_t meta = s_meta[wid][ri];
       const int rlen = (int)REC_LEN(meta);
@@ -523,13 +523,14 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
         img[0] = i0.x; img[1] = i0.y; img[2] = i0.z; img[3] = i0.w; img[4] = i1.x; img[5] = i1.y; img[6] = i1.z; img[7] = i1.w;
         c[7] &= 0xFFFFu;
         const uint32_t exact0 = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
-        w = ctx_score<ULEN>(img, c, sh, k, mp, W, exact0, REC_BUDGET(meta), ri, ULEN ? ulen : (uint32_t)rlen);
+        w = ctx_score<ULEN>(img, c, sh, k, mp, W, exact0, REC_BUDGET(meta), ri, ULEN ? ulen : (uint32_t)rlen, lm);
       }
       return w;
     };
 
     // ---- phase B
-    auto process = [&](auto ulen_tag, int k, int q1, uint32_t sh, int rr, const uint4& a, const uint4& b2) {
+    auto process = [&](auto ulen_tag, int k, int q1, uint32_t sh, const uint32_t (&lm)[8], int rr, const uint4& a,
+                       const uint4& b2) {
       // (opaque: the probes of round rr belong to the same reads for every window; the compiler
       // would otherwise keep what it derives from them in registers across the window loop)
       const uint32_t ri = opaque((uint32_t)rr * 16 + (lane >> 2));
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       const uint32_t jx = part == 1 ? j0 : (part == 2 ? j1 : j2);
       uint32_t c[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
       const bool live = part >= 1 && part - 1 < cnt && !(dbg & 1);
-      const uint32_t w = compare(ulen_tag, (uint32_t)k, q1, sh, ri, jx, live, c);
+      const uint32_t w = compare(ulen_tag, (uint32_t)k, q1, sh, lm, ri, jx, live, c);
       report(w, gene, jx - (uint32_t)q1);
     };
     {
@@ -561,9 +562,17 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
           // masks derived from it live for these four rounds only
           const int q1 = W2 ? (k == 0 ? win0 : win1) : mp->win[k];
           const uint32_t sh = opaque_s(2u * (uint32_t)(CL - q1));
+          // the window's length-mask row: eight scalars for these four rounds
+          uint32_t lm[8];
+          {
+            constexpr bool ULEN = decltype(ulen_tag)::value;
+            const uint32_t* __restrict__ row = mp->lm[ULEN ? __builtin_amdgcn_readfirstlane((int)ulen) : 0][k];
+#pragma unroll
+            for (int j = 0; j < 8; j++) lm[j] = ULEN ? row[j] : 0u;
+          }
 #pragma unroll
           for (int rr = 0; rr < 4; rr++) {
-            process(ulen_tag, k, q1, sh, rr, va[rr % MATCH_RING], vb[rr % MATCH_RING]);
+            process(ulen_tag, k, q1, sh, lm, rr, va[rr % MATCH_RING], vb[rr % MATCH_RING]);
             // refill the slot with the round MATCH_RING ahead (this window's, or the next one's)
             if (rr + MATCH_RING < 4) issue(k, rr + MATCH_RING, va[rr % MATCH_RING], vb[rr % MATCH_RING]);
             else if (k + 1 < W) issue(k + 1, rr + MATCH_RING - 4, va[rr % MATCH_RING], vb[rr % MATCH_RING]);
@@ -627,9 +636,15 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
             if (!__any(mine)) continue;
             const int q1k = W2 ? (kk == 0 ? win0 : win1) : mp->win[kk];
             const uint32_t shk = opaque_s(2u * (uint32_t)(CL - q1k));
+            uint32_t lmk[8];
+            {
+              const uint32_t* __restrict__ row = mp->lm[ulen != 0xFFFFFFFFu ? __builtin_amdgcn_readfirstlane((int)ulen) : 0][kk];
+#pragma unroll
+              for (int j = 0; j < 8; j++) lmk[j] = row[j];
+            }
             uint32_t w2;
-            if (ulen != 0xFFFFFFFFu) w2 = compare(std::true_type{}, (uint32_t)kk, q1k, shk, seg, jx, mine, c);
-            else w2 = compare(std::false_type{}, (uint32_t)kk, q1k, shk, seg, jx, mine, c);
+            if (ulen != 0xFFFFFFFFu) w2 = compare(std::true_type{}, (uint32_t)kk, q1k, shk, lmk, seg, jx, mine, c);
+            else w2 = compare(std::false_type{}, (uint32_t)kk, q1k, shk, lmk, seg, jx, mine, c);
             if (mine) {
               w = w2;
               q1 = q1k;

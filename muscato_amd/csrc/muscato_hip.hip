@@ -123,7 +123,9 @@ struct musc_ctx {
 
   // database
   uint32_t* db2 = nullptr;
-  uint32_t* dbm2 = nullptr;  // null when the database holds no X
+  uint32_t* dbm2 = nullptr;  // null when the database holds no X (or an all-zero plane made for reads that do)
+  bool db_has_x = false;     // the database holds an X
+  bool reads_have_x = false; // some loaded read holds an X
   uint32_t* dbx = nullptr;   // with dbm2: one bit per 64-base block that holds an X
   uint64_t* seq_off = nullptr;
   uint32_t nseq = 0;
@@ -327,6 +329,7 @@ void free_db(musc_ctx* c) {
   if (c->dbx) (void)hipFree(c->dbx);
   if (c->seq_off) (void)hipFree(c->seq_off);
   c->db2 = c->dbm2 = c->dbx = nullptr;
+  c->db_has_x = false;
   c->seq_off = nullptr;
   c->nseq = 0;
   c->nbases = 0;
@@ -337,6 +340,7 @@ void free_reads(musc_ctx* c) {
   if (c->rd) (void)hipFree(c->rd);
   if (c->rdm) (void)hipFree(c->rdm);
   c->rd = c->rdm = nullptr;
+  c->reads_have_x = false;
   c->nreads = 0;
   c->rw = 0;
   c->data_epoch++;
@@ -548,6 +552,7 @@ static int db_finish(musc_ctx* c) {
   uint32_t hasx = 0;
   HIPCHK(c, hipMemcpyAsync(&hasx, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->db_has_x = hasx != 0;
   if (!hasx) {
     (void)hipFree(c->dbm2);
     c->dbm2 = nullptr;
@@ -845,7 +850,9 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
 static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL) {
   if (const char* e = getenv("MUSC_INDEX"))
     if (strcmp(e, "classic") == 0) return false;
-  if (c->dbm2 || c->rdm) return false;
+  // (the planes themselves may exist without an X: an all-zero one is made for the side that has
+  // none when the other side does, and the database's stays for the context's lifetime)
+  if (c->db_has_x || c->reads_have_x) return false;
   if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
   if (P->n_windows > CTX_MAX_W) return false;
   int q1min = P->windows[0], q1max = P->windows[0];
@@ -952,6 +959,7 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
   uint32_t hasx = 0;
   HIPCHK(c, hipMemcpyAsync(&hasx, d_hasx, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->reads_have_x = hasx != 0;
   if (!hasx) {
     (void)hipFree(c->rdm);
     c->rdm = nullptr;
@@ -1268,7 +1276,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   if (!ev0 || !ev1) return fail(c, 10, "hipEventCreate failed");
   HIPCHK(c, hipEventRecord(ev0, c->stream));
 
-  const bool mask = c->rdm || c->dbm2;
+  const bool mask = c->reads_have_x || c->db_has_x;  // (a stale all-zero plane of an earlier batch does not count)
   // a mask plane on only one side: allocate the missing all-zero plane once
   if (mask && !c->rdm && c->nreads) {
     const uint64_t words = c->nreads * (uint64_t)c->rw;

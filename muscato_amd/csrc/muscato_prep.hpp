@@ -259,6 +259,7 @@ extern "C" int musc_reads_sort_unique(musc_ctx* c, const char* seqs, const uint6
     free(h_ustart);
     return fail(c, 10, "musc_reads_sort_unique: %s", hipGetErrorString(e));
   }
+  c->reads_have_x = hasx != 0;
   if (!hasx) {
     (void)hipFree(c->rdm);
     c->rdm = nullptr;

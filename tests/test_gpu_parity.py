@@ -490,3 +490,54 @@ def test_block_screening_falls_back_to_exact_counters(eng):
         full = orc.match_direct(reads, targets, ocfg)
         assert_same(gpu_hits(eng, ocfg, reads, targets, False), as_arr(full))
         assert eng.stats()["n_overflow_blocks"] == 0
+
+
+def test_index_selection(monkeypatch):
+    """Which index a run gets (ensure_index): context buckets + the fused k_match when every read
+    fits 120 bases of context around each of at most four windows and nothing holds an X; the
+    64-byte buckets and k_screen -> k_confirm otherwise -- with identical tuples either way."""
+    from muscato_amd import Config, Engine, sorted_hits
+    monkeypatch.delenv("MUSC_INDEX", raising=False)
+    rng = random.Random(2)
+    targets = [rand_seq(rng, 400, b"ACGT") for _ in range(40)]
+
+    def reads_of(L, n=200, alphabet=b"ACGT"):
+        out = set()
+        for _ in range(n):
+            t = rng.choice(targets)
+            p = rng.randint(0, len(t) - L)
+            out.add(mutate(rng, t[p:p + L], 0.02, alphabet))
+        return sorted(out)
+
+    cases = [
+        ("two windows, 100 bp: exactly 120 bases of context", [0, 20], 100, b"ACGT", 1),
+        ("one base too many", [0, 21], 100, b"ACGT", 0),
+        ("four windows, 90 bp", [0, 10, 20, 30], 90, b"ACGT", 1),
+        ("five windows", [0, 5, 10, 15, 20], 90, b"ACGT", 0),
+        ("reads with X", [0, 20], 100, b"ACGTX", 0),
+        ("long reads", [0, 20], 150, b"ACGT", 0),
+    ]
+    with Engine(0) as eng:
+        eng.load_targets(targets)
+        for what, wins, L, alphabet, kind in cases:
+            reads = reads_of(L, alphabet=alphabet)
+            ocfg = orc.Config(Windows=wins, WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=L, MaxMatches=100000, MMTol=1)
+            eng.load_reads(reads)
+            got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+            assert eng.stats()["index_kind"] == kind, what
+            assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
+        # forced
+        monkeypatch.setenv("MUSC_INDEX", "classic")
+        reads = reads_of(100)
+        ocfg = orc.Config(Windows=[0, 20], WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=100, MaxMatches=100000)
+        eng.load_reads(reads)
+        got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+        assert eng.stats()["index_kind"] == 0
+        assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
+        # musc_db_build_index_for builds what the match then uses (no rebuild: the timing stays)
+        monkeypatch.delenv("MUSC_INDEX", raising=False)
+        eng.build_index_for(to_cfg(ocfg), 100)
+        ms = eng.stats()["ms_index_build"]
+        got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+        assert eng.stats()["index_kind"] == 1 and eng.stats()["ms_index_build"] == ms
+        assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
