@@ -12,6 +12,7 @@ are concatenated on rank 0 over RCCL (N>1, inside the timed region).  `value` is
 steady-state figure (`config.timed_region` says so); beside it the line carries
   * `survey_scope`  SURVEY.md 8d's timer: packed reads in pinned host memory -> upload -> match
                     -> tuples in pinned host memory (PCIe both ways; never `value`),
+  * `graph_replay`  the sized pass replayed as one hipGraph launch (MUSC_GRAPH=1, opt-in),
   * `first_pass_ms` one pass over freshly loaded reads (the sizing pass the CLI always takes),
     `cold_pass_ms`  the first pass of the process (buffer allocation included),
   * `roofline`      the dominant kernel against the HBM roofline, on the bytes it loads,
@@ -447,6 +448,27 @@ def main() -> int:
         legs["pcie_inclusive"] = {"ms_per_step": (time.perf_counter() - t1) * 1e3,
                                   "what": "sized pass + tuples copied to pinned host memory (no read upload)"}
         legs["pcie_inclusive"]["reads_per_s"] = wl.n_raw_reads / (legs["pcie_inclusive"]["ms_per_step"] / 1e3)
+
+        if st["index_kind"] == 1:
+            # (1b) the same sized pass replayed as one hipGraph launch (MUSC_GRAPH=1, opt-in): what is
+            # left of the host's share once the seven launches per batch are one
+            os.environ["MUSC_GRAPH"] = "1"
+            try:
+                for _ in range(2):  # capture, first replay
+                    assert match() == n0
+                torch.cuda.synchronize()
+                dev_ms = 0.0
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    assert match() == n0
+                    dev_ms += eng.stats()["ms_total"]
+                wall = (time.perf_counter() - t1) * 1e3 / args.steps
+                legs["graph_replay"] = {"ms_per_pass": wall, "device_ms": dev_ms / args.steps,
+                                        "host_overhead_ms": wall - dev_ms / args.steps,
+                                        "reads_per_s": wl.n_raw_reads / (wall / 1e3),
+                                        "what": "MUSC_GRAPH=1: sized pass as one hipGraphLaunch + one stream sync"}
+            finally:
+                os.environ.pop("MUSC_GRAPH", None)
 
         if not args.no_survey_scope and not args.unsorted and args.xrate == 0:
             # (2) SURVEY.md 8d's timer scope (reference wall: cmd/muscato/main.go:306-420, screen ->

@@ -202,6 +202,13 @@ struct musc_ctx {
   bool sized_exact_blocks = false;
   uint32_t sized_bsz = 0;        // reads per batch it ended up with
   musc_stats stats;
+  // MUSC_GRAPH=1: the sized pass on context buckets as a hipGraph (one launch instead of seven per
+  // batch; no per-kernel timing in that mode)
+  hipGraphExec_t graph_exec = nullptr;
+  uint64_t graph_epoch = 0;
+  musc_params graph_params;
+  int graph_block_mode = -1;
+  uint32_t graph_batches = 0;
   // timing events are created once and reused by every pass (creating and destroying a pair per
   // kernel family per batch cost more than the kernels of a small pass)
   std::vector<hipEvent_t> ev_pool;
@@ -363,9 +370,11 @@ hipEvent_t pool_event(musc_ctx* c) {
 // HIP-event timing of the kernel families of one pass; the events belong to the context's pool
 struct Timer {
   musc_ctx* c;
+  bool off = false;  // while a pass is captured into a hipGraph no events are recorded
   std::vector<EvPair> ev[5];
   explicit Timer(musc_ctx* ctx) : c(ctx) { c->ev_used = 0; }
   int begin(int fam, hipStream_t s = nullptr) {
+    if (off) return 0;
     EvPair p;
     p.a = pool_event(c);
     p.b = pool_event(c);
@@ -375,7 +384,7 @@ struct Timer {
     return 0;
   }
   void end(int fam, hipStream_t s = nullptr) {
-    if (!ev[fam].empty()) (void)hipEventRecord(ev[fam].back().b, s ? s : c->stream);
+    if (!off && !ev[fam].empty()) (void)hipEventRecord(ev[fam].back().b, s ? s : c->stream);
   }
   float total(int fam) {
     float t = 0;
@@ -527,6 +536,7 @@ void musc_destroy(musc_ctx* c) {
   for (hipEvent_t ev : {c->ev_ready[0], c->ev_ready[1], c->ev_free[0], c->ev_free[1], c->ev_join})
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1056,19 +1066,42 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
                      memcmp(&c->sized_params, P, sizeof *P) == 0 && !getenv("MUSC_DEBUG_SYNC");
   uint32_t bsz = sized ? c->sized_bsz : c->batch_reads;
   const uint64_t L = c->max_len;
+  // A sized pass can be replayed as a hipGraph (MUSC_GRAPH=1): its launches, the counter memsets
+  // and the final readback are captured once per (reads, database, parameters) and then cost one
+  // launch per pass.  Every buffer of a sized pass is fixed, so the captured arguments stay valid;
+  // any pass that sizes drops the graph.
+  const char* genv = getenv("MUSC_GRAPH");
+  const bool use_graph = sized && genv && atoi(genv) > 0;
+  if (!sized && c->graph_exec) {
+    (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+  }
   for (int attempt = 0;; attempt++) {
     if (attempt > 40) return fail(c, 12, "internal: the context pass did not converge on buffer sizes");
     Timer tm(c);
     hipEvent_t ev0 = pool_event(c), ev1 = pool_event(c);
     if (!ev0 || !ev1) return fail(c, 10, "hipEventCreate failed");
-    HIPCHK(c, hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), c->stream));
-    if (block_mode == 2) HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
-    HIPCHK(c, hipEventRecord(ev0, c->stream));
+    const bool replay = use_graph && c->graph_exec && c->graph_epoch == c->data_epoch && c->graph_block_mode == block_mode &&
+                        memcmp(&c->graph_params, P, sizeof *P) == 0;
+    const bool capture = use_graph && !replay;
+    if (capture && c->graph_exec) {
+      (void)hipGraphExecDestroy(c->graph_exec);
+      c->graph_exec = nullptr;
+    }
+    tm.off = capture || replay;
+    if (!replay) {
+      if (capture) HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      else HIPCHK(c, hipEventRecord(ev0, c->stream));
+    }
     uint64_t n_cand = 0, n_cmp = 0, n_windows = 0, n_ovf = 0, r0 = 0;
     c->stats.n_batches = 0;
     c->stats.match_launches = 0;
     bool again = false;
-    while (r0 < c->nreads) {
+    if (!replay) {
+      HIPCHK(c, hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), c->stream));
+      if (block_mode == 2) HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
+    }
+    while (!replay && r0 < c->nreads) {
       const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
       const uint32_t ntiles = nblk(n, WT);  // wave-tiles of 64 reads
       const uint64_t sgrid = std::min<uint64_t>(nblk(n, TILE), resident);
@@ -1137,13 +1170,35 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     c->last_pp = pp;
     c->last_max_matches = (uint32_t)max_matches;
     c->last_exact_blocks = block_mode == 2;
-    if (block_mode == 2) {
-      hipLaunchKernelGGL(k_block_overflow, dim3(1024), dim3(256), 0, c->stream, c->block_table.p, (uint32_t)max_matches,
-                         c->counters);
-      HIPCHK(c, hipGetLastError());
+    if (!replay) {
+      if (block_mode == 2) {
+        hipLaunchKernelGGL(k_block_overflow, dim3(1024), dim3(256), 0, c->stream, c->block_table.p, (uint32_t)max_matches,
+                           c->counters);
+        HIPCHK(c, hipGetLastError());
+      }
+      if (!capture) HIPCHK(c, hipEventRecord(ev1, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 16 * 8, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipEventRecord(ev1, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->counters, 16 * 8, hipMemcpyDeviceToHost, c->stream));
+    if (capture) {
+      hipGraph_t g = nullptr;
+      HIPCHK(c, hipStreamEndCapture(c->stream, &g));
+      const hipError_t ge = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (ge != hipSuccess) {
+        c->graph_exec = nullptr;
+        return fail(c, 10, "hipGraphInstantiate failed: %s", hipGetErrorString(ge));
+      }
+      c->graph_epoch = c->data_epoch;
+      c->graph_params = *P;
+      c->graph_block_mode = block_mode;
+      c->graph_batches = c->stats.n_batches;
+    }
+    if (capture || replay) {
+      c->stats.n_batches = c->stats.match_launches = c->graph_batches;
+      HIPCHK(c, hipEventRecord(ev0, c->stream));
+      HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+      HIPCHK(c, hipEventRecord(ev1, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->h_pinned[3]) {
       if (!sized) return fail(c, 12, "internal: a capacity guard fired although every batch was sized (flags %llu)",

@@ -1,6 +1,6 @@
 """Long-running fuzz of the GPU path (not collected by pytest): `python tests/fuzz_gpu.py LO HI`
 runs make_case(seed) for seed in [LO, HI) through one Engine -- all accepted tuples, best+MMTol
-twice (the second pass is sync-free), and the same reads through the GPU read prep -- against
+three times (the later passes are sync-free; with MUSC_GRAPH=1 the last is a graph replay), and the same reads through the GPU read prep -- against
 the Python oracle.  Round 1: seeds 0..100000 with the final kernels, no mismatch (270 s on one MI355X); round 2 (context
 buckets + k_match wherever a case fits them): seeds 0..90000, no mismatch (308 s)."""
 import os
@@ -22,7 +22,7 @@ for seed in range(lo, hi):
     best = sorted(orc.best_filter(full, ocfg.MMTol))
     e.load_targets(targets); e.load_reads(reads)
     cfg = Config(Windows=list(ocfg.Windows), WindowWidth=ocfg.WindowWidth, PMatch=ocfg.PMatch, MinDinuc=ocfg.MinDinuc, MaxReadLength=ocfg.MaxReadLength, MaxMatches=ocfg.MaxMatches, MMTol=ocfg.MMTol, MatchMode=ocfg.MatchMode)
-    for mode, exp in ((False, full), (True, best), (True, best)):
+    for mode, exp in ((False, full), (True, best), (True, best), (True, best)):  # sizing, sized, (MUSC_GRAPH=1: captured, replayed)
         got = [tuple(int(x) for x in r) for r in sorted_hits(e.match(cfg, apply_mmtol=mode))]
         if got != exp:
             bad += 1

@@ -541,3 +541,38 @@ def test_index_selection(monkeypatch):
         got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
         assert eng.stats()["index_kind"] == 1 and eng.stats()["ms_index_build"] == ms
         assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
+
+
+@pytest.mark.gpu
+def test_graph_replay_of_the_sized_pass(monkeypatch):
+    """MUSC_GRAPH=1: from the second identical pass on, the context-bucket pass is one hipGraph
+    launch (memsets, k_match, scan, k_compact_w, counter readback).  Tuples and counters must equal
+    the launch-by-launch pass, and new reads, new parameters or a different tuple selection must
+    drop the captured graph instead of replaying stale arguments."""
+    from muscato_amd import Engine, sorted_hits
+    monkeypatch.delenv("MUSC_INDEX", raising=False)
+    keys = ("n_hits", "n_pairs", "n_candidates", "n_read_windows", "n_accepted", "n_overflow_blocks", "n_overflow_entries",
+            "index_kind", "n_batches", "match_launches", "match_bytes")
+    with Engine(0) as eng:
+        for seed in (5, 6):
+            rng = random.Random(seed)
+            targets = [rand_seq(rng, 600, b"ACGT") for _ in range(60)]
+            eng.load_targets(targets)
+            for L, wins, mm in ((100, [0, 20], 1), (80, [0, 15, 30], 0)):
+                reads = sorted({mutate(rng, (t := rng.choice(targets))[(p := rng.randint(0, 600 - L)):p + L], 0.03, b"ACGT")
+                                for _ in range(3000)})
+                ocfg = orc.Config(Windows=wins, WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=L, MaxMatches=100000, MMTol=mm)
+                eng.load_reads(reads)
+                for mode in (True, False):
+                    monkeypatch.delenv("MUSC_GRAPH", raising=False)
+                    exp = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=mode))
+                    st0 = eng.stats()
+                    assert st0["index_kind"] == 1
+                    monkeypatch.setenv("MUSC_GRAPH", "1")
+                    for rep in range(3):  # capture, replay, replay
+                        got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=mode))
+                        st = eng.stats()
+                        assert (got == exp).all() and all(st[k] == st0[k] for k in keys), (seed, L, mode, rep)
+                        assert st["ms_total"] > 0
+                full = as_arr(orc.match_direct(reads, targets, ocfg))
+                assert_same(exp, full)
