@@ -208,16 +208,21 @@ def main() -> int:
     # Rehearsal knobs (never set by the driver): run N ranks on ONE card over gloo to exercise
     # the N>1 control flow where only one GPU exists (RCCL refuses two ranks on one device).
     backend = os.environ.get("MUSC_BENCH_BACKEND", "nccl")
+    # MUSC_BENCH_FORCE_DIST=1 with one rank: a one-member RCCL group, so that the N>1 code (device
+    # buffers filled by the library, counts agreed by all_reduce on the device, the gatherer's
+    # stream handling) runs on a one-GPU box; only the transfers themselves have no peer
+    multi = world > 1 or bool(os.environ.get("MUSC_BENCH_FORCE_DIST"))
     if "MUSC_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["MUSC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = synth.workload_for(args.workload, world)
     strong = wl.total_raw_reads is not None
@@ -302,8 +307,8 @@ def main() -> int:
             % (n_raw, prep["distinct"], prep["read_prep_device_ms"], prep["read_prep_wall_s"], prep["equals_torch_sort"]))
     del roff, toff
     n_loaded = eng.n_reads
-    keep_for_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    keep_reads = keep_for_cpu or (world == 1 and not args.no_survey_scope)
+    keep_for_cpu = (rank == 0 and not multi and not args.no_cpu_baseline)
+    keep_reads = keep_for_cpu or (not multi and not args.no_survey_scope)
     if not keep_for_cpu:
         del targets
     if not keep_reads:
@@ -321,7 +326,7 @@ def main() -> int:
     cold_device_ms = eng.stats()["ms_total"]
 
     read_base = rank * n_loaded if not strong else None
-    if world > 1:
+    if multi:
         # global read numbers: rank r's reads follow those of ranks 0..r-1
         cnt = torch.tensor([n_loaded], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
         cnts = [torch.zeros_like(cnt) for _ in range(world)]
@@ -334,7 +339,7 @@ def main() -> int:
     gathered_n = [0]
     gatherer = None
     gather_mode = "none"
-    if world > 1:
+    if multi:
         # The tuples of every pass end up on rank 0 in rank order (= global read order).  The
         # gather of pass i (grouped send/recv into rank 0's rank-major buffer, counts ride in the
         # buffers) runs on the communicator's stream while pass i+1 is matched; capacity agreed once.
@@ -398,7 +403,7 @@ def main() -> int:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -424,7 +429,7 @@ def main() -> int:
             gathered_n[0] = sum(cnts)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -435,7 +440,7 @@ def main() -> int:
     st = eng.stats()
 
     legs = {}
-    if world == 1:
+    if not multi:
         import numpy as np
         # (1) steady-state pass + D2H of the tuples into PINNED host memory (the r01 figure used pageable)
         nmax = int(n0 * 1.05) + 16
@@ -648,7 +653,7 @@ def main() -> int:
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(res), flush=True)
     eng.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return rc

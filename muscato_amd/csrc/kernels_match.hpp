@@ -401,7 +401,13 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   const bool apply = mp->apply_mmtol != 0;
 
   // phase A of wave-tile wt (best-buffer `par`); returns the tile's common read length or ~0
-  auto phase_a = [&](uint32_t wt, uint32_t par) -> uint32_t {
+  // the records of wave-tile wt, a lane per read
+  auto fetch = [&](uint32_t wt, Rec<RW>& rec) {
+    const uint32_t lane = opaque(threadIdx.x) & 63;
+    const uint32_t i = wt * WT + lane;
+    rec.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);
+  };
+  auto phase_a = [&](uint32_t wt, uint32_t par, const Rec<RW>& rec) -> uint32_t {
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6;
     uint32_t* const img_l = s_img[wid];
@@ -409,8 +415,6 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
     uint32_t* const wcnt_l = s_dyn + wid * WT * W;
     const uint32_t i = wt * WT + lane;
     const bool active = i < n;
-    Rec<RW> rec;
-    rec.load(rd + (r0 + (active ? i : 0)) * (uint64_t)RW, RW);
     const int len = (int)rec.len();
     uint32_t valid = 0;
     for (int k = 0; k < W; k++) {
@@ -447,8 +451,9 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6, part = lane & 3;
     const uint32_t b = s_bb[wid][k * WT + rr * 16 + (lane >> 2)];
-    a = make_uint4(0, 0, 0, 0);
-    b2 = make_uint4(0, 0, 0, 0);
+    // a probe that takes no part reads as an empty bucket: count 0, and nothing else of the
+    // registers (they keep the previous round's words) is looked at
+    a.x = 0;
     if (b != WB_NONE && !(dbg & 2)) {
       const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b) + 2 * part;
       const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
@@ -462,9 +467,13 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   // lines in flight (phases A..C share the per-tile LDS state; D needs only the candidate list and
   // the tile's own best[] buffer).
   uint4 va[MATCH_RING], vb[MATCH_RING];
+#pragma unroll
+  for (int rr = 0; rr < MATCH_RING; rr++) va[rr] = vb[rr] = make_uint4(0, 0, 0, 0);
   uint32_t ulen = 0xFFFFFFFFu, par = 0;
   if (gw < nwt) {
-    ulen = phase_a(gw, 0);
+    Rec<RW> rec;
+    fetch(gw, rec);
+    ulen = phase_a(gw, 0, rec);
     wave_lds_sync();
 #pragma unroll
     for (int rr = 0; rr < MATCH_RING; rr++) issue(0, rr, va[rr], vb[rr]);
@@ -509,8 +518,12 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       constexpr bool ULEN = decltype(ulen_tag)::value;
       const uint32_t meta = s_meta[wid][ri];
       const int rlen = (int)REC_LEN(meta);
+      // placements past the target's first bases (p = jx - q1 > 0) only have to end inside the
+      // target; the pos-0 rules are evaluated only when some lane of the wave is at p <= 0
       uint32_t z = 0;
-      const bool ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, rlen, &z);
+      bool ok;
+      if (__any(live && jx <= (uint32_t)q1)) ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, rlen, &z);
+      else ok = live & (rlen - q1 <= (int)(c[7] >> 16));
       uint32_t w = NX_REJECT;
       {
         const unsigned long long okv = __ballot(ok);  // counted by the scalar unit, credited to one lane
@@ -582,6 +595,8 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       if (ulen != 0xFFFFFFFFu) rounds(std::true_type{}); else rounds(std::false_type{});
     }
     wave_lds_sync();
+
+    const bool have_next = wt + nw < nwt;
 
     // ---- phase C: the overflow entries of the wave-tile's W x 64 probes, MATCH_WOWN per chunk
     if (!(dbg & 4)) {
@@ -676,8 +691,10 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
       wave_lds_sync();  // phases A..C of this tile are done with the per-tile LDS state
       // the next wave-tile: phase A and the loads of its first rounds, in flight during phase D
       uint32_t ulen_next = 0xFFFFFFFFu;
-      if (wt + nw < nwt) {
-        ulen_next = phase_a(wt + nw, par ^ 1u);
+      if (have_next) {
+        Rec<RW> nrec;
+        fetch(wt + nw, nrec);
+        ulen_next = phase_a(wt + nw, par ^ 1u, nrec);
         wave_lds_sync();
 #pragma unroll
         for (int rr = 0; rr < MATCH_RING; rr++) issue(0, rr, va[rr], vb[rr]);

@@ -80,13 +80,18 @@ class OracleEngine:
         pass
 
 
-def _worker(rank, world, port, seed, outdir, use_gpu):
+def _worker(rank, world, port, seed, outdir, use_gpu, backend="gloo"):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    on_dev = backend == "nccl"  # RCCL moves device buffers: the library fills them in place
+    if on_dev:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from cases import make_case
     from muscato_amd import Config
     from muscato_amd.dist import HitGatherer, shard_range
@@ -103,7 +108,7 @@ def _worker(rank, world, port, seed, outdir, use_gpu):
         eng = OracleEngine(ocfg, targets)
     eng.load_reads(reads[lo:hi])
     n0 = eng.match_device(cfg, apply_mmtol=True, n_shards=world)
-    dev = torch.device("cpu")
+    dev = torch.device("cuda", 0) if on_dev else torch.device("cpu")
     out = {}
     for packed in (False, True):
         g = HitGatherer(HitGatherer.agree_capacity(n0, dev), dev, depth=2, packed=packed)
@@ -112,21 +117,21 @@ def _worker(rank, world, port, seed, outdir, use_gpu):
 
             def fill(buf, n=n):
                 if n and packed:
-                    eng.hits_to_packed(buf.data_ptr(), n, False, BITS, lo)
+                    eng.hits_to_packed(buf.data_ptr(), n, on_dev, BITS, lo)
                 elif n:
-                    eng.hits_to(buf.data_ptr(), n, False)
+                    eng.hits_to(buf.data_ptr(), n, on_dev)
                 return n
             g.submit(fill, lo)
         cn = g.finish()
         # the MaxMatches proof is per shard: the union holds only if every shard reports 0
-        o = torch.tensor([int(eng.stats()["n_overflow_blocks"])], dtype=torch.int64)
+        o = torch.tensor([int(eng.stats()["n_overflow_blocks"])], dtype=torch.int64, device=dev)
         dist.all_reduce(o, op=dist.ReduceOp.MAX)
         if rank == 0:
             res = g.last_result()
-            out["packed" if packed else "plain"] = (cn, HitGatherer.unpack(res, BITS) if packed else res.to(torch.int64),
+            out["packed" if packed else "plain"] = (cn, (HitGatherer.unpack(res, BITS) if packed else res.to(torch.int64)).cpu(),
                                                     int(o.item()))
     # the compact form: one count byte per read + one u32 word per tuple
-    nmax = torch.tensor([eng.n_reads], dtype=torch.int64)
+    nmax = torch.tensor([eng.n_reads], dtype=torch.int64, device=dev)
     dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
     g = HitGatherer(HitGatherer.agree_capacity(n0, dev), dev, depth=2, compact_reads=int(nmax.item()))
     for _ in range(3):
@@ -134,16 +139,16 @@ def _worker(rank, world, port, seed, outdir, use_gpu):
 
         def fillc(buf, n=n):
             counts, words = g.compact_views(buf)
-            eng.hits_to_compact(words.data_ptr(), g.cap, counts.data_ptr(), g.compact_reads, False, CBITS)
+            eng.hits_to_compact(words.data_ptr(), g.cap, counts.data_ptr(), g.compact_reads, on_dev, CBITS)
             return n, eng.n_reads
         g.submit(fillc, lo)
     cn = g.finish()
-    bases = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(bases, torch.tensor([lo], dtype=torch.int64))
+    bases = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(bases, torch.tensor([lo], dtype=torch.int64, device=dev))
     if rank == 0:
         slabs = g.last_slabs()
         res = torch.cat([g.unpack_compact(slabs[r], int(bases[r]), CBITS) for r in range(world)], dim=0)
-        out["compact"] = (cn, res, 0)
+        out["compact"] = (cn, res.cpu(), 0)
         torch.save(out, os.path.join(outdir, "out.pt"))
     if not use_gpu:
         assert eng.n_shards_seen and all(s == world for s in eng.n_shards_seen)
@@ -152,11 +157,11 @@ def _worker(rank, world, port, seed, outdir, use_gpu):
     dist.destroy_process_group()
 
 
-def _check(tmp_path, seed, use_gpu):
+def _check(tmp_path, seed, use_gpu, world=2, backend="gloo"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cases import make_case
     from oracle import muscato_oracle as orc
-    mp.spawn(_worker, args=(2, _free_port(), seed, str(tmp_path), use_gpu), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), seed, str(tmp_path), use_gpu, backend), nprocs=world, join=True)
     out = torch.load(tmp_path / "out.pt")
     ocfg, reads, targets = make_case(seed)
     exp = sorted(orc.best_filter(orc.match_direct(reads, targets, ocfg), ocfg.MMTol))
@@ -179,6 +184,17 @@ def test_two_rank_engine_shaped_gather_cpu(tmp_path, seed):
 @pytest.mark.parametrize("seed", [3, 14, 27])
 def test_two_rank_engines_share_one_gpu(tmp_path, seed):
     _check(tmp_path, seed, use_gpu=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 14])
+def test_one_member_rccl_group_with_device_buffers(tmp_path, seed):
+    """What the gloo runs cannot reach: backend "nccl" (RCCL) with the gatherer's buffers in device
+    memory, filled in place by musc_hits_copy / _packed / _compact (dst_on_device = 1), counts
+    agreed by collectives on device tensors, the communicator's stream against the library's.  One
+    GPU allows one RCCL rank, so the group has a single member and no transfer has a peer; the
+    8-GPU run adds only torch's own grouped send/recv."""
+    _check(tmp_path, seed, use_gpu=True, world=1, backend="nccl")
 
 
 @pytest.mark.gpu
