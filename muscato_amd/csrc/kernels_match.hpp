@@ -177,7 +177,9 @@ inline void match_tables(MatchParams& mp) {
 }
 
 
+#ifndef MATCH_SKETCH_BITS
 #define MATCH_SKETCH_BITS 10
+#endif
 
 // fit rules of one index entry for a read of rlen bases placed through the window at q1:
 // p = jx - q1 >= 0; target position 0 takes the pos-0 path of processSeq with its literal 100
@@ -202,14 +204,16 @@ DEV bool ctx_fit(uint32_t jx, uint32_t rem16, int q1, int ww, int rlen, uint32_t
 
 // utils/entropy.go:5-40 for a window of at most 16 bases without X: the window is one 32-bit
 // word, a dinucleotide one 4-bit field of it (rec_count_dinuc is the general form)
-template <class R>
-DEV int rec_count_dinuc16(const R& r, uint32_t q1, int ww) {
-  const uint32_t key = (uint32_t)r.ext(2 * q1);
+DEV int key_count_dinuc16(uint32_t key, int ww) {
   uint32_t seen = 0;
 #pragma unroll
   for (int i = 0; i < 15; i++)
     if (i + 1 < ww) seen |= 1u << ((key >> (2 * i)) & 15u);
   return __popc(seen);
+}
+template <class R>
+DEV int rec_count_dinuc16(const R& r, uint32_t q1, int ww) {
+  return key_count_dinuc16((uint32_t)r.ext(2 * q1), ww);
 }
 
 // The read's IMAGE for window k: its bases moved to where the context stream holds the target

@@ -41,6 +41,7 @@
 #include "kernels_screen.hpp"
 #include "kernels_confirm.hpp"
 #include "kernels_match.hpp"
+#include "kernels_match_dense.hpp"
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -1003,14 +1004,50 @@ static size_t match_dyn_lds(int W, int block_mode) {
   return block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;  // TILE = 4 waves x 64
 }
 
-// workgroups of k_match that are resident at once on this device: the persistent grid
+// Which of the two kernels on context buckets runs: k_match_d (dense comparison passes,
+// kernels_match_dense.hpp) where its LDS budget allows three workgroups per CU -- at most two
+// windows and records of at most eight words -- and k_match (comparison where the line arrives)
+// otherwise.  MUSC_MATCH=quad forces k_match.
+static bool match_dense(const musc_ctx* c, int W) {
+  const char* e = getenv("MUSC_MATCH");
+  if (e && !strcmp(e, "quad")) return false;
+  return W <= 2 && c->rw <= 8;
+}
+
+// workgroups of the kernel that are resident at once on this device: the persistent grid
 template <int RW>
 static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
   int per_cu = 0, ncu = 0;
   const size_t lds = match_dyn_lds(W, block_mode);
-  hipError_t e = w2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, true>, TILE, lds)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, false>, TILE, lds);
+  hipError_t e;
+  if constexpr (RW <= 8) {
+    if (match_dense(c, W)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match_d<RW, true>, TILE, lds);
+    else e = w2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, true>, TILE, lds)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, false>, TILE, lds);
+  } else {
+    e = w2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, true>, TILE, lds)
+           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, false>, TILE, lds);
+  }
   if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
+  // The occupancy query counts LDS to the byte; the hardware hands it out in larger pieces
+  // (measured on gfx950: 3 x 54 208 B did not fit a CU's 160 KB, 3 x 52 160 B did), and a grid one
+  // workgroup per CU too large runs its last third as a second round (+45 % on cfg3).  Bound the
+  // count with 2 KB pieces.
+  {
+    hipFuncAttributes fa;
+    const void* fn = nullptr;
+    if constexpr (RW <= 8) {
+      if (match_dense(c, W)) fn = reinterpret_cast<const void*>(&k_match_d<RW, true>);
+    }
+    if (!fn) fn = w2 ? reinterpret_cast<const void*>(&k_match<RW, true>) : reinterpret_cast<const void*>(&k_match<RW, false>);
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess) {
+      const size_t total = ((size_t)fa.sharedSizeBytes + lds + 2047) / 2048 * 2048;
+      const int fit = total ? (int)((160u << 10) / total) : per_cu;
+      if (fit >= 1 && fit < per_cu) per_cu = fit;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
   return (unsigned)per_cu * (unsigned)ncu;
 }
@@ -1020,11 +1057,17 @@ static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, i
                          unsigned ngrid) {
   const dim3 grid(ngrid), block(TILE);
   const size_t lds = match_dyn_lds(W, block_mode);
-#define MUSC_LAUNCH_MATCH(W2)                                                                                     \
-  hipLaunchKernelGGL((k_match<RW, W2>), grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,       \
+#define MUSC_LAUNCH_MATCH(K)                                                                                      \
+  hipLaunchKernelGGL(K, grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,                       \
                      c->ctx_T, c->ctx_E, c->stage.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,    \
                      c->tcount2.p, block_mode, block_thr, c->block_table.p, c->counters)
-  if (w2) MUSC_LAUNCH_MATCH(true); else MUSC_LAUNCH_MATCH(false);
+  if constexpr (RW <= 8) {
+    if (match_dense(c, W)) {
+      MUSC_LAUNCH_MATCH((k_match_d<RW, true>));
+      return;
+    }
+  }
+  if (w2) MUSC_LAUNCH_MATCH((k_match<RW, true>)); else MUSC_LAUNCH_MATCH((k_match<RW, false>));
 #undef MUSC_LAUNCH_MATCH
 }
 }  // extern "C++"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # k_match with parts switched off (MUSC_DEBUG_MATCH: 1 no comparisons, 2 no bucket loads, 4 no overflow lists)
-for d in 0 1 2 3 4 5 7; do
+for d in ${DBGS:-0 1 2 3 4 5 7}; do
   MUSC_DEBUG_MATCH=$d timeout -k 10 200 python bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 5 > gpurun_out/dbg_$d.json 2> gpurun_out/dbg_$d.err
   python - <<PY
 import json

@@ -41,18 +41,22 @@ def _hamming_ok(T_flat, TL, R, h, L, chunk=2_000_000):
     return True
 
 
-@pytest.mark.parametrize("name,index", [("cfg3", "auto"), ("cfg3", "classic"), ("cfg5shard", "auto")])
+@pytest.mark.parametrize("name,index", [("cfg3", "auto"), ("cfg3", "quad"), ("cfg3", "classic"), ("cfg5shard", "auto")])
 def test_baseline_config_at_full_size(name, index, monkeypatch):
     """index "auto": what the library picks -- context buckets + the fused k_match for cfg3 (two
     windows, 100-bp reads: 120 bases of context), the 64-byte-bucket index + k_screen -> k_confirm
     for the cfg5 shard (three windows do not fit the context; 10 Gbp would not fit the table);
     "classic" forces the latter for cfg3 as well."""
     import torch
-    if index == "classic":
+    monkeypatch.delenv("MUSC_MATCH", raising=False)
+    if index == "quad":  # context buckets with k_match instead of k_match_d
+        monkeypatch.setenv("MUSC_MATCH", "quad")
+        monkeypatch.delenv("MUSC_INDEX", raising=False)
+    elif index == "classic":
         monkeypatch.setenv("MUSC_INDEX", "classic")
     else:
         monkeypatch.delenv("MUSC_INDEX", raising=False)
-    want_kind = 1 if (name, index) == ("cfg3", "auto") else 0
+    want_kind = 1 if name == "cfg3" and index in ("auto", "quad") else 0
     from muscato_amd import Config, Engine, sorted_hits, synth
     from oracle import literal
     from oracle import muscato_oracle as orc

@@ -19,25 +19,30 @@ from cases import make_case, mutate, rand_seq
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "classic"])
+@pytest.fixture(scope="module", params=["auto", "quad", "classic"])
 def eng(request):
-    """Every test of this module runs twice: on the index the library picks by itself (context
-    buckets + the fused k_match wherever the run fits them, see kernels_match.hpp) and with
-    MUSC_INDEX=classic (64-byte buckets, k_screen -> k_confirm)."""
+    """Every test of this module runs three times: on what the library picks by itself (context
+    buckets wherever the run fits them, with k_match_d -- dense comparison passes,
+    kernels_match_dense.hpp -- for up to two windows and k_match otherwise), with MUSC_MATCH=quad
+    (context buckets, always k_match) and with MUSC_INDEX=classic (64-byte buckets, k_screen ->
+    k_confirm)."""
     from muscato_amd import Engine
-    old = os.environ.get("MUSC_INDEX")
+    old = {k: os.environ.get(k) for k in ("MUSC_INDEX", "MUSC_MATCH")}
+    os.environ.pop("MUSC_INDEX", None)
+    os.environ.pop("MUSC_MATCH", None)
     if request.param == "classic":
         os.environ["MUSC_INDEX"] = "classic"
-    else:
-        os.environ.pop("MUSC_INDEX", None)
+    elif request.param == "quad":
+        os.environ["MUSC_MATCH"] = "quad"
     e = Engine(0)
     e.index_mode = request.param
     yield e
     e.close()
-    if old is None:
-        os.environ.pop("MUSC_INDEX", None)
-    else:
-        os.environ["MUSC_INDEX"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def to_cfg(ocfg):
