@@ -55,7 +55,10 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
                                                      uint32_t* __restrict__ tbase, uint32_t* __restrict__ tcount2,
                                                      int block_mode, uint32_t block_thr,
                                                      uint32_t* __restrict__ block_table,
-                                                     unsigned long long* __restrict__ counters) {
+                                                     unsigned long long* __restrict__ counters,
+                                                     const uint4* __restrict__ pstage, const uint32_t* __restrict__ ptcount2,
+                                                     const uint32_t* __restrict__ ptpre, uint32_t pnwt,
+                                                     uint4* __restrict__ hits, uint64_t hits_cap) {
   constexpr int WMAX = W2 ? 2 : CTX_MAX_W;
   constexpr int NWAVE = TILE / 64;
   constexpr int RPAD = 8;  // words in front of and behind a wave's records that a shifted window may touch
@@ -178,6 +181,40 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
     }
   };
 
+  // The tuples the PREVIOUS batch's launch staged (pstage != nullptr: same grid, same regions, the
+  // other stage buffer) move to their final place in `hits` from inside this launch: the wave that
+  // staged wave-tile wt of that batch copies it while it matches its own wave-tile wt -- the copy's
+  // memory time hides under the comparisons instead of a k_compact_w launch between two launches.
+  bool pcopy = pstage != nullptr;
+  unsigned long long pbase = 0;
+  if (pcopy) {
+    pbase = counters[2];
+    if (pbase + ptpre[pnwt] > hits_cap) {  // cannot happen on a sized pass
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&counters[3], 2ull);
+      pcopy = false;
+    }
+  }
+  uint64_t pused = 0;  // tuples of the previous batch this wave has moved (its region is consumed in order)
+  auto pcopy_begin = [&](uint32_t wt, uint4& v, uint32_t& m, uint32_t& d) {
+    m = 0;
+    d = 0;
+    if (pcopy && wt < pnwt) {
+      const uint32_t wtu = (uint32_t)__builtin_amdgcn_readfirstlane((int)wt);
+      m = ptcount2[wtu];
+      d = ptpre[wtu];
+      const uint32_t lane = opaque(threadIdx.x) & 63;
+      if (lane < m) v = pstage[region0 + pused + lane];
+    }
+  };
+  auto pcopy_end = [&](const uint4& v, uint32_t m, uint32_t d) {
+    if (!m) return;
+    const uint32_t lane = opaque(threadIdx.x) & 63;
+    uint4* __restrict__ dst = hits + pbase + d;
+    if (lane < m) dst[lane] = v;
+    for (uint32_t i = 64 + lane; i < m; i += 64) dst[i] = pstage[region0 + pused + i];  // a tile with more than 64 tuples
+    pused += m;
+  };
+
   uint4 va[MATCH_RING], vb[MATCH_RING];
 #pragma unroll
   for (int rr = 0; rr < MATCH_RING; rr++) va[rr] = vb[rr] = make_uint4(0, 0, 0, 0);
@@ -192,7 +229,11 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
 #pragma unroll
     for (int rr = 0; rr < MATCH_RING; rr++) issue(0, 0, rr, va[rr], vb[rr]);
   }
-  for (uint32_t wt = gw; wt < nwt; wt += nw) {
+  uint32_t wt = gw;
+  for (; wt < nwt; wt += nw) {
+    uint4 cpv = make_uint4(0, 0, 0, 0);
+    uint32_t cpm, cpd;
+    pcopy_begin(wt, cpv, cpm, cpd);
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6, part = lane & 3;
     uint32_t* const bb_l = s_bb[par][wid];
@@ -392,6 +433,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
       // lines have been on their way since this tile's last window)
       uint32_t ulen_next = 0xFFFFFFFFu;
       if (have_next) ulen_next = phase_a2(wt + nw, par ^ 1u, nrec, nvalid_next);
+      pcopy_end(cpv, cpm, cpd);
       cnt_l[lane] = 0;  // the stack becomes cnt / base
       wave_lds_sync();
       auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) -> uint32_t {
@@ -445,6 +487,14 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
       ulen = ulen_next;
       par ^= 1u;
       wave_lds_sync();  // the next wave-tile's phase B rewrites the stack / the candidate list
+    }
+  }
+  if (pcopy) {
+    for (; wt < pnwt; wt += nw) {
+      uint4 cpv = make_uint4(0, 0, 0, 0);
+      uint32_t cpm, cpd;
+      pcopy_begin(wt, cpv, cpm, cpd);
+      pcopy_end(cpv, cpm, cpd);
     }
   }
   // one reduction per workgroup and a handful of atomics from its first thread (as in k_match)

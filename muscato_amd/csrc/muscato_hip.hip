@@ -176,6 +176,9 @@ struct musc_ctx {
   hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_join = nullptr;
   DevBuf<uint32_t> scan_tmp, tcount2, tpre;
   DevBuf<uint4> stage;
+  // k_match_d moves the tuples a batch staged from inside the NEXT batch's launch: a second set
+  DevBuf<uint32_t> tcount2_b, tpre_b;
+  DevBuf<uint4> stage_b;
   DevBuf<uint32_t> p_nx;
   DevBuf<uint16_t> nmiss_tab;
   DevBuf<uint32_t> block_table;
@@ -525,6 +528,7 @@ void musc_destroy(musc_ctx* c) {
     c->bs[i].cdesc.release();
   }
   c->scan_tmp.release(); c->tcount2.release(); c->tpre.release(); c->stage.release();
+  c->tcount2_b.release(); c->tpre_b.release(); c->stage_b.release();
   c->p_nx.release();
   c->nmiss_tab.release();
   c->block_table.release();
@@ -1052,18 +1056,25 @@ static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
   return (unsigned)per_cu * (unsigned)ncu;
 }
 
+// set: which staging buffers the launch fills (0: stage / tcount2, 1: stage_b / tcount2_b);
+// prev_tiles > 0: the launch also moves the other set's tuples (the previous batch's) into `hits`
 template <int RW>
 static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr,
-                         unsigned ngrid) {
+                         unsigned ngrid, int set = 0, uint32_t prev_tiles = 0) {
   const dim3 grid(ngrid), block(TILE);
   const size_t lds = match_dyn_lds(W, block_mode);
-#define MUSC_LAUNCH_MATCH(K)                                                                                      \
+  DevBuf<uint4>& st = set ? c->stage_b : c->stage;
+  DevBuf<uint32_t>& tc = set ? c->tcount2_b : c->tcount2;
+#define MUSC_LAUNCH_MATCH(K, ...)                                                                                 \
   hipLaunchKernelGGL(K, grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,                       \
-                     c->ctx_T, c->ctx_E, c->stage.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,    \
-                     c->tcount2.p, block_mode, block_thr, c->block_table.p, c->counters)
+                     c->ctx_T, c->ctx_E, st.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,          \
+                     tc.p, block_mode, block_thr, c->block_table.p, c->counters, ##__VA_ARGS__)
   if constexpr (RW <= 8) {
     if (match_dense(c, W)) {
-      MUSC_LAUNCH_MATCH((k_match_d<RW, true>));
+      const uint4* pst = prev_tiles ? (set ? c->stage.p : c->stage_b.p) : nullptr;
+      const uint32_t* ptc = set ? c->tcount2.p : c->tcount2_b.p;
+      const uint32_t* ptp = set ? c->tpre.p : c->tpre_b.p;
+      MUSC_LAUNCH_MATCH((k_match_d<RW, true>), pst, ptc, ptp, prev_tiles, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap);
       return;
     }
   }
@@ -1119,6 +1130,12 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
   }
+  const bool fuse = sized && c->nreads > bsz && c->rw <= 8 && match_dense(c, pp.W) && !getenv("MUSC_NO_FUSED_COMPACT");
+  if (fuse) {  // the second staging set (a sized pass: every capacity is known; allocated once, outside any capture)
+    if ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
+        (rc = ensure(c, c->tpre_b, c->tpre.cap)))
+      return rc;
+  }
   for (int attempt = 0;; attempt++) {
     if (attempt > 40) return fail(c, 12, "internal: the context pass did not converge on buffer sizes");
     Timer tm(c);
@@ -1144,6 +1161,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       HIPCHK(c, hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), c->stream));
       if (block_mode == 2) HIPCHK(c, hipMemsetAsync(c->block_table.p, 0, (1ull << BLOCK_TABLE_BITS) * 4, c->stream));
     }
+    int set = 0;
+    uint32_t pending_tiles = 0;  // wave-tiles of the previous batch whose tuples are still staged
     while (!replay && r0 < c->nreads) {
       const uint32_t n = (uint32_t)std::min<uint64_t>(bsz, c->nreads - r0);
       const uint32_t ntiles = nblk(n, WT);  // wave-tiles of 64 reads
@@ -1158,17 +1177,28 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         if ((rc = ensure(c, c->spill, swaves * 16))) return rc;
         HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
       }
+      // A sized pass of k_match_d over several batches: the tuples batch b staged are moved into
+      // `hits` by the launch of batch b + 1 (other staging set, same grid so the same regions);
+      // only the last batch needs k_compact_w.
+      const bool more = r0 + n < c->nreads;
+      const uint64_t next_grid = more ? std::min<uint64_t>(nblk((uint32_t)std::min<uint64_t>(bsz, c->nreads - r0 - n), TILE), resident) : 0;
+      const bool defer = fuse && more && next_grid == sgrid;  // this batch's tuples wait for the next launch
       tm.begin(0);
       {
         Range rg("k_match");
       switch (c->rw) {
-        case 4: launch_match<4>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid); break;
-        case 8: launch_match<8>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid); break;
+        case 4: launch_match<4>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
+        case 8: launch_match<8>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
         default: launch_match<12>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid); break;
       }
       }
       HIPCHK(c, hipGetLastError());
       tm.end(0);
+      if (pending_tiles) {  // the previous batch is in `hits` now
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, set ? c->tpre.p : c->tpre_b.p, pending_tiles, c->counters);
+        HIPCHK(c, hipGetLastError());
+        pending_tiles = 0;
+      }
       c->stats.match_launches++;
       c->stats.n_batches++;
       if (!sized) {
@@ -1198,14 +1228,21 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       Range rgc("scan + k_compact_w");
       tm.begin(4);
       tm.begin(1);
-      rc = scan_u32(c, c->tcount2.p, c->tpre.p, (uint64_t)ntiles + 1, false, c->scan_tmp.p, c->stream);
+      rc = scan_u32(c, set ? c->tcount2_b.p : c->tcount2.p, set ? c->tpre_b.p : c->tpre.p, (uint64_t)ntiles + 1, false,
+                    c->scan_tmp.p, c->stream);
       if (rc) return rc;
       tm.end(1);
-      hipLaunchKernelGGL(k_compact_w, dim3(std::min(nblk(ntiles, 4), 4u * MAX_GRID)), dim3(256), 0, c->stream, ntiles, c->bs[0].tbase.p, c->tcount2.p,
-                         c->tpre.p, c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap, c->counters);
-      HIPCHK(c, hipGetLastError());
-      hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, c->tpre.p, ntiles, c->counters);
-      HIPCHK(c, hipGetLastError());
+      if (defer) {
+        pending_tiles = ntiles;
+        set ^= 1;
+      } else {
+        hipLaunchKernelGGL(k_compact_w, dim3(std::min(nblk(ntiles, 4), 4u * MAX_GRID)), dim3(256), 0, c->stream, ntiles,
+                           c->bs[0].tbase.p, set ? c->tcount2_b.p : c->tcount2.p, set ? c->tpre_b.p : c->tpre.p,
+                           set ? c->stage_b.p : c->stage.p, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap, c->counters);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, c->stream, set ? c->tpre_b.p : c->tpre.p, ntiles, c->counters);
+        HIPCHK(c, hipGetLastError());
+      }
       tm.end(4);
       r0 += n;
     }

@@ -119,6 +119,18 @@ def test_baseline_config_at_full_size(name, index, monkeypatch):
         assert NT < (1 << 24) and TL <= (1 << 10) and U < (1 << 26)
         skey = torch.sort(key).values
         assert bool((skey[1:] != skey[:-1]).all()), "the union over windows is not a set"
+        # the same pass again: sized now (no host round trips; with k_match_d the tuples of a batch
+        # are moved into place by the next batch's launch) -- the same list, tuple for tuple
+        assert eng.match_device(cfg, apply_mmtol=False) == n_all
+        st2 = eng.stats()
+        assert st2["n_batches"] == st["n_batches"] and st2["n_pairs"] == st["n_pairs"]
+        h2 = torch.empty((n_all, 4), dtype=torch.int32, device=dev)
+        eng.hits_to(h2.data_ptr(), n_all, True)
+        assert bool((h2[:, 0].to(torch.int64)[1:] >= h2[:, 0].to(torch.int64)[:-1]).all()), "not read-major"
+        h2 = h2.to(torch.int64)
+        skey2 = torch.sort((h2[:, 0] << 34) | (h2[:, 1] << 10) | h2[:, 2]).values
+        assert bool((skey2 == skey).all()), "the sized pass returns different tuples"
+        del h2, skey2
         # planted reads: one that matches its source verbatim (not at target position 0, where the
         # literal-100 rule blinds window 0 for reads longer than 100 - ww) must be reported there
         # with nmiss 0 unless none of its windows passes the MinDinuc gate
