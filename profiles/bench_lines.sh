@@ -11,6 +11,9 @@ python bench.py --workload cfg5shard --steps 10 --warmup 3 --no-cpu-baseline > $
 # two ranks on ONE GPU over gloo (RCCL refuses two ranks on one device): the N>1 control flow only
 MUSC_BENCH_BACKEND=gloo MUSC_BENCH_DEVICE=0 MUSC_INDEX=classic timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
   --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 1 --reads 5000000 > $o/${tag}_n2_rehearsal.json 2> $o/${tag}_n2_rehearsal.err || { echo "n2 FAILED"; tail -5 $o/${tag}_n2_rehearsal.err; }
+# one rank in an RCCL group: the N>1 code with device buffers (the transfers have no peer)
+MUSC_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --workload cfg4shard --steps 10 --warmup 2 > $o/${tag}_rccl1_rehearsal.json 2> $o/${tag}_rccl1_rehearsal.err || { echo "rccl1 FAILED"; tail -5 $o/${tag}_rccl1_rehearsal.err; }
+MUSC_GRAPH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_cfg3_graph_bench.json 2>/dev/null || echo "cfg3 graph FAILED"
 for f in cfg3 cfg3_classic cfg2 cfg4shard cfg5shard n2_rehearsal; do
   python - <<PY
 import json

@@ -4,8 +4,8 @@
 # Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ and the summaries next to it; copy
 # gpurun_out/<tag>_* into profiles/ afterwards.  Counters are collected in their own passes (never
 # together with --kernel-trace/--stats), one counter group per pass.  Two index kinds: "auto" = what
-# the library picks for cfg3 (context buckets, k_match) and "classic" (64-byte buckets, k_screen ->
-# k_confirm).
+# the library picks for cfg3 (context buckets, k_match_d) and "classic" (64-byte buckets, k_screen ->
+# k_confirm); the kernel statistics also with MUSC_MATCH=quad (context buckets, k_match).
 set -o pipefail
 tag=${1:-r02}
 out=gpurun_out/prof_$tag
@@ -30,11 +30,15 @@ for kind in auto classic; do
     fi
   done
 done
+# k_match (the kernel k_match_d replaced for up to two windows), kernel statistics only
+MUSC_MATCH=quad timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_quad -- python3 bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 5 > $out/stats_quad.log 2>&1 || tail -3 $out/stats_quad.log
+f=$(find $out/stats_quad -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && grep -E "^\"?Name|k_" "$f" > gpurun_out/${tag}_cfg3_quad_kernel_stats.csv
 # roctx ranges of the library (marker trace is not a counter pass)
 timeout -k 10 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $out/marker -- python3 bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 3 > $out/marker.log 2>&1 || tail -3 $out/marker.log
 f=$(find $out/marker -name "*marker_api_stats.csv" -o -name "*marker*stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${tag}_cfg3_marker_stats.csv
 python3 profiles/pmc_summary.py $out > gpurun_out/${tag}_cfg3_pmc_summary.txt
-python3 profiles/traffic_from_pmc.py $out cfg3 k_match k_screen k_confirm k_compact > gpurun_out/${tag}_traffic.json
+python3 profiles/traffic_from_pmc.py $out cfg3 k_match_d k_match k_screen k_confirm k_compact_w k_compact > gpurun_out/${tag}_traffic.json
 rm -rf $out/pmc_* $out/stats_*/*/*.db 2>/dev/null; du -sh $out; cat gpurun_out/${tag}_cfg3_auto_kernel_stats.csv | head -8
 cat gpurun_out/${tag}_traffic.json | head -60
