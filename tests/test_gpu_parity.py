@@ -581,3 +581,49 @@ def test_graph_replay_of_the_sized_pass(monkeypatch):
                         assert st["ms_total"] > 0
                 full = as_arr(orc.match_direct(reads, targets, ocfg))
                 assert_same(exp, full)
+
+
+def test_batches_of_heavy_tiles_move_their_tuples_in_the_next_launch(monkeypatch):
+    """Families of near-identical targets: a read has dozens of tuples, a wave-tile thousands (copy
+    loops past the first 64, candidate lists spilling past LDS), in many small batches.  From the
+    second pass on k_match_d moves a batch's staged tuples from inside the next batch's launch
+    (last batch: k_compact_w; a last batch with a smaller grid: k_compact_w for the one before as
+    well).  Every pass must return the single-batch list of the two-kernel path, in read-major
+    order, with and without best + MMTol."""
+    from muscato_amd import Engine, sorted_hits
+    rng = np.random.default_rng(77)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    fam = bases[rng.integers(0, 4, size=(12, 400))]
+    T = np.repeat(fam, 30, axis=0)  # 12 families x 30 copies
+    sub = rng.random(T.shape) < 0.01
+    T[sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    targets = [bytes(t) for t in T]
+    g = rng.integers(0, len(targets), size=30000)
+    p = rng.integers(0, 400 - 80 + 1, size=30000)
+    R = T[g[:, None], p[:, None] + np.arange(80)[None, :]].copy()
+    sub = rng.random(R.shape) < 0.01
+    R[sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    reads = sorted({bytes(r) for r in R})
+    ocfg = orc.Config(Windows=[0, 25], WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=80,
+                      MaxMatches=1_000_000_000, MMTol=1)
+    monkeypatch.delenv("MUSC_MATCH", raising=False)
+    monkeypatch.setenv("MUSC_INDEX", "classic")
+    with Engine(0) as ref:
+        ref.load_targets(targets)
+        ref.load_reads(reads)
+        exp_all = sorted_hits(ref.match(to_cfg(ocfg), apply_mmtol=False))
+        exp_best = sorted_hits(ref.match(to_cfg(ocfg), apply_mmtol=True))
+    assert len(exp_all) > 20 * len(reads)
+    monkeypatch.delenv("MUSC_INDEX", raising=False)
+    for batch in ("4099", "8192", "7000"):  # 7000: the last batch of 30 000 has a smaller grid
+        monkeypatch.setenv("MUSC_BATCH_READS", batch)  # read at musc_init
+        with Engine(0) as eng:
+            eng.load_targets(targets)
+            eng.load_reads(reads)
+            for mode, exp in ((False, exp_all), (True, exp_best)):
+                for rep in range(3):  # pass 0 sizes, passes 1-2 are sized (same parameters as the pass before)
+                    raw = eng.match(to_cfg(ocfg), apply_mmtol=mode)
+                    st = eng.stats()
+                    assert st["index_kind"] == 1 and st["n_batches"] == -(-len(reads) // int(batch))
+                    assert (np.diff(raw[:, 0].astype(np.int64)) >= 0).all(), "the hit list is not read-major"
+                    assert_same(sorted_hits(raw), exp)
