@@ -87,10 +87,21 @@ class HitGatherer:
         shape, dtype = ((self.cap + 1,), torch.int64) if packed else ((self.cap + 1, 4), torch.int32)
         if self.compact_reads:
             shape, dtype = (2 + self.cw + self.cap,), torch.int32
-        self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self.recv = None
         if self.rank == dst:
+            # the destination fills its own slab of the receive buffer in place: its shard never
+            # touches a link, nor a second buffer
             self.recv = [torch.empty((self.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
+            for r in self.recv:
+                r[self.rank].zero_()
+            self.send = [r[self.rank] for r in self.recv]
+        else:
+            self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
+        # the counts of a pass reach a device buffer through one small pinned staging tensor per
+        # buffer set (one asynchronous copy instead of a blocking scalar write per field)
+        self.head = None
+        if torch.device(device).type == "cuda":
+            self.head = [torch.zeros(2, dtype=dtype, pin_memory=True) for _ in range(depth)]
         self.work = [None] * depth
         self.i = 0
 
@@ -123,16 +134,25 @@ class HitGatherer:
         if n > self.cap:
             raise RuntimeError("HitGatherer: %d hits exceed the agreed capacity %d" % (n, self.cap))
         if self.compact_reads:
-            buf[0] = n
-            buf[1] = int(nreads)
+            if self.head is not None:
+                h = self.head[k]  # (free again: the transfers of `depth` passes ago were waited for)
+                h[0] = n
+                h[1] = int(nreads)
+                buf[:2].copy_(h, non_blocking=True)
+            else:
+                buf[0] = n
+                buf[1] = int(nreads)
         elif self.packed:
-            buf[self.cap] = n
+            if self.head is not None:
+                self.head[k][0] = n
+                buf[self.cap:].copy_(self.head[k][:1], non_blocking=True)
+            else:
+                buf[self.cap] = n
         else:
             if read_base and n:
                 buf[:n, 0] += read_base
             buf[self.cap, 0] = n
         if self.rank == self.dst:
-            self.recv[k][self.rank].copy_(buf)  # the destination's own shard never touches a link
             ops = [dist.P2POp(dist.irecv, self.recv[k][r], r, self.group) for r in range(self.world) if r != self.dst]
         else:
             ops = [dist.P2POp(dist.isend, buf, self.dst, self.group)]
