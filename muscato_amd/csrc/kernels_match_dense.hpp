@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
   extern __shared__ uint32_t s_dyn[];  // block_mode != 0: NWAVE x W x 64 per-(window, read) counters, then (mode 1) the sketch
   __shared__ uint32_t s_rec[NWAVE][WT * RW + 2 * RPAD];  // the wave-tile's records
   __shared__ uint32_t s_meta[NWAVE][WT];                  // length | budget << 17 | valid windows << 24
-  __shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, read), WB_NONE when the window takes no part; this tile's and the next one's
+__shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, read), WB_NONE when the window takes no part; this tile's and the next one's
   __shared__ uint32_t s_oc[NWAVE][WT];                    // current window: overflow entries of the probe
   __shared__ uint32_t s_ovf[NWAVE][WT];                   // current window: where in E
   __shared__ uint32_t s_best[NWAVE][WT];                  // smallest mismatch count reported per read

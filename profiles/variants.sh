@@ -1,7 +1,9 @@
 #!/bin/bash
-# cfg3 device times of library variants: profiles/variants.sh build_variants/a.so build_variants/b.so ...
+# cfg3 device times of library variants: profiles/variants.sh [bench flags --] build_variants/a.so build_variants/b.so ...
+flags=""
+if [ "$1" = "--flags" ]; then flags="$2"; shift 2; fi
 for lib in "$@"; do
-  MUSC_LIB_PATH=$PWD/$lib timeout -k 10 200 python bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 5 > gpurun_out/var.json 2> gpurun_out/var.err
+  MUSC_LIB_PATH=$PWD/$lib timeout -k 10 200 python bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 10 $flags > gpurun_out/var.json 2> gpurun_out/var.err
   python - <<PY
 import json
 try:
