@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
   extern __shared__ uint32_t s_dyn[];  // block_mode != 0: NWAVE x W x 64 per-(window, read) counters, then (mode 1) the sketch
   __shared__ uint32_t s_rec[NWAVE][WT * RW + 2 * RPAD];  // the wave-tile's records
   __shared__ uint32_t s_meta[NWAVE][WT];                  // length | budget << 17 | valid windows << 24
-__shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, read), WB_NONE when the window takes no part; this tile's and the next one's
+  __shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, read), WB_NONE when the window takes no part; this tile's and the next one's
   __shared__ uint32_t s_oc[NWAVE][WT];                    // current window: overflow entries of the probe
   __shared__ uint32_t s_ovf[NWAVE][WT];                   // current window: where in E
   __shared__ uint32_t s_best[NWAVE][WT];                  // smallest mismatch count reported per read
@@ -106,7 +106,7 @@ __shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, re
   //       MinDinuc (cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185)
   //       and the bucket of the window key -> s_bb[par].  Runs before the current tile's last
   //       window, whose arrival steps refill the ring with the next tile's first steps.
-  //   a2  after the current tile's last comparison pass: the record -> LDS, the meta word, best[].
+  //   a2  after the current tile's last comparison pass: the record -> LDS and the meta word.
   auto fetch = [&](uint32_t wt, Rec<RW>& rec) {
     const uint32_t i = wt * WT + (opaque(threadIdx.x) & 63);
     rec.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);
@@ -149,7 +149,7 @@ __shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, re
     return valid;
   };
   // returns the tile's common read length or ~0
-  auto phase_a2 = [&](uint32_t wt, uint32_t par, const Rec<RW>& rec, uint32_t valid) -> uint32_t {
+  auto phase_a2 = [&](uint32_t wt, const Rec<RW>& rec, uint32_t valid) -> uint32_t {
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6;
     uint32_t* const wcnt_l = s_dyn + wid * WT * W;
@@ -224,7 +224,7 @@ __shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, re
     Rec<RW> rec;
     fetch(gw, rec);
     const uint32_t valid = phase_a1(gw, 0, rec);
-    ulen = phase_a2(gw, 0, rec, valid);
+    ulen = phase_a2(gw, rec, valid);
     wave_lds_sync();
 #pragma unroll
     for (int rr = 0; rr < MATCH_RING; rr++) issue(0, 0, rr, va[rr], vb[rr]);
@@ -432,7 +432,7 @@ __shared__ uint32_t s_bb[2][NWAVE][WMAX * WT];          // bucket of (window, re
       // the next wave-tile's records and meta words take the place of this one's (its first bucket
       // lines have been on their way since this tile's last window)
       uint32_t ulen_next = 0xFFFFFFFFu;
-      if (have_next) ulen_next = phase_a2(wt + nw, par ^ 1u, nrec, nvalid_next);
+      if (have_next) ulen_next = phase_a2(wt + nw, nrec, nvalid_next);
       pcopy_end(cpv, cpm, cpd);
       cnt_l[lane] = 0;  // the stack becomes cnt / base
       wave_lds_sync();
