@@ -1130,14 +1130,15 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
   }
-  const bool fuse = sized && c->nreads > bsz && c->rw <= 8 && match_dense(c, pp.W) && !getenv("MUSC_NO_FUSED_COMPACT");
-  if (fuse) {  // the second staging set (a sized pass: every capacity is known; allocated once, outside any capture)
+  const bool fuse_ok = c->rw <= 8 && match_dense(c, pp.W) && !getenv("MUSC_NO_FUSED_COMPACT");
+  if (sized && fuse_ok && c->nreads > bsz) {  // the second staging set (allocated outside any capture)
     if ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
         (rc = ensure(c, c->tpre_b, c->tpre.cap)))
       return rc;
   }
   for (int attempt = 0;; attempt++) {
     if (attempt > 40) return fail(c, 12, "internal: the context pass did not converge on buffer sizes");
+    const bool fuse = fuse_ok && c->nreads > bsz;  // (a sizing pass may have halved the batch size)
     Timer tm(c);
     hipEvent_t ev0 = pool_event(c), ev1 = pool_event(c);
     if (!ev0 || !ev1) return fail(c, 10, "hipEventCreate failed");
@@ -1175,9 +1176,12 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
         if ((rc = ensure(c, c->stage, std::max<uint64_t>(2ull * n, swaves * 64)))) return rc;
         if ((rc = ensure(c, c->spill, swaves * 16))) return rc;
+        if (fuse && ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
+                     (rc = ensure(c, c->tpre_b, c->tpre.cap))))
+          return rc;
         HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
       }
-      // A sized pass of k_match_d over several batches: the tuples batch b staged are moved into
+      // A pass of k_match_d over several batches: the tuples batch b staged are moved into
       // `hits` by the launch of batch b + 1 (other staging set, same grid so the same regions);
       // only the last batch needs k_compact_w.
       const bool more = r0 + n < c->nreads;
