@@ -176,6 +176,8 @@ def main() -> int:
     ap.add_argument("--no-block-check", action="store_true", help="skip the MaxMatches per-block overflow check")
     ap.add_argument("--index", choices=["auto", "classic"], default="auto",
                     help="classic: force the 64-byte-bucket index and the two-kernel path (MUSC_INDEX=classic)")
+    ap.add_argument("--x-reads-only", action="store_true",
+                    help="with --xrate: X (N in the FASTQ) in the reads alone, the database stays X-free (reads with X on context buckets)")
     ap.add_argument("--xrate", type=float, default=0.0,
                     help="fraction of bases replaced by X in targets and reads (the correctness/timing run with the mask planes)")
     args = ap.parse_args()
@@ -240,7 +242,7 @@ def main() -> int:
     if args.xrate > 0:
         gx = torch.Generator(device=device)
         gx.manual_seed(seed + 99)
-        for s0 in range(0, wl.n_targets, 100_000):
+        for s0 in range(0, 0 if args.x_reads_only else wl.n_targets, 100_000):
             blk = targets[s0:s0 + 100_000]
             blk[torch.rand(blk.shape, device=device, generator=gx) < args.xrate] = ord("X")
     toff = synth.offsets_for(wl.n_targets, wl.target_len, device)
@@ -617,7 +619,7 @@ def main() -> int:
                 "targets": wl.n_targets, "target_len": wl.target_len, "read_len": wl.read_len,
                 "Windows": list(wl.windows), "WindowWidth": wl.window_width, "PMatch": wl.pmatch,
                 "MMTol": wl.mmtol, "MinDinuc": wl.min_dinuc, "MaxMatches": wl.max_matches,
-                "MatchMode": wl.match_mode, "x_rate": args.xrate, "read_order": "random" if args.unsorted else "bytewise sorted (reads_sorted)",
+                "MatchMode": wl.match_mode, "x_rate": args.xrate, "x_in": ("reads" if args.x_reads_only else "reads and database") if args.xrate else None, "read_order": "random" if args.unsorted else "bytewise sorted (reads_sorted)",
                 "parallelism": "reads sharded x%d, database replicated" % world, "gather": gather_mode,
                 "timed_region": "`value`: steady state -- unique reads + database + index resident in HBM -> hits in HBM"
                                 + (" gathered on rank 0 (RCCL, gather of pass i overlapped with pass i+1)" if world > 1 else "")

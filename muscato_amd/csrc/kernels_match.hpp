@@ -257,10 +257,12 @@ DEV void read_image(const Rec<RW>& rec, uint32_t sh, uint32_t (&img)[8]) {
 //            rows of the host's tables then, read by the scalar unit; otherwise the length mask is
 //            per lane arithmetic
 //   lm     : ULEN: the row mp->lm[len][k], loaded by the caller once per window (eight scalars)
-template <bool ULEN>
+//   XM     : xm[] marks (in the image's coordinates, one bit per base like the length mask) the
+//            bases of the read that are X: with an X-free database they mismatch wherever they land
+template <bool ULEN, bool XM = false>
 DEV uint32_t ctx_score(const uint32_t (&img)[8], const uint32_t (&c)[8], uint32_t sh, uint32_t k,
                        const MatchParams* __restrict__ mp, int W, uint32_t exact0, uint32_t budget, uint32_t slot,
-                       uint32_t len, const uint32_t (&lm)[8]) {
+                       uint32_t len, const uint32_t (&lm)[8], const uint32_t (&xm)[8]) {
   uint32_t d[8];
   uint32_t nx = 0;
   // (readfirstlane: tells the compiler the index is wave-uniform, so the rows are read by scalar loads)
@@ -271,7 +273,7 @@ DEV uint32_t ctx_score(const uint32_t (&img)[8], const uint32_t (&c)[8], uint32_
     uint32_t m;
     if constexpr (ULEN) m = lm[j];
     else m = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
-    d[j] = (x | (x >> 1)) & m;
+    d[j] = XM ? ((x | (x >> 1)) | xm[j]) & m : (x | (x >> 1)) & m;
     nx += __popc(d[j]);
   }
   uint32_t exact = exact0;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
         img[0] = i0.x; img[1] = i0.y; img[2] = i0.z; img[3] = i0.w; img[4] = i1.x; img[5] = i1.y; img[6] = i1.z; img[7] = i1.w;
         c[7] &= 0xFFFFu;
         const uint32_t exact0 = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
-        w = ctx_score<ULEN>(img, c, sh, k, mp, W, exact0, REC_BUDGET(meta), ri, ULEN ? ulen : (uint32_t)rlen, lm);
+        w = ctx_score<ULEN>(img, c, sh, k, mp, W, exact0, REC_BUDGET(meta), ri, ULEN ? ulen : (uint32_t)rlen, lm, lm);
       }
       return w;
     };

@@ -45,7 +45,51 @@
 #define MATCH_QW 12      // words per stack entry (48 bytes: three aligned b128 accesses)
 #define MATCH_DOWN 48    // overflow items moved per step
 
-template <int RW, bool W2>
+// Reads with X on context buckets (RX): with an X-free database an X in a read is a mismatch wherever
+// the read is placed, and a window holding one never finds its key in the index.  What the kernel
+// needs of a read's X is where they are: xpos = up to four positions (7 bits each, bits 0-27) and
+// their number (bits 28-31, saturating at 15).  A read with more than four X takes part only if
+// that many mismatches exceed its budget anyway -- then it has no tuples at all (k_xpos_check
+// makes the run take the two-kernel path otherwise).
+#define XPOS_MAX 4
+#define XPOS_CNT(w) ((w) >> 28)
+#define XPOS_AT(w, q) (((w) >> (7 * (q))) & 127u)
+
+__global__ void k_read_xpos(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm, uint64_t nreads, int rw,
+                            uint32_t* __restrict__ xpos) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  uint32_t w = 0;
+  if (rd[(i + 1) * rw - 1] & READ_HAS_X) {
+    uint32_t cnt = 0;
+    for (int j = 0; j < rw - 1; j++) {
+      uint32_t m = rdm[i * rw + j] & 0x55555555u;
+      while (m) {
+        const uint32_t b = (uint32_t)__ffs(m) - 1u;
+        m &= m - 1u;
+        const uint32_t p = 16u * (uint32_t)j + (b >> 1);
+        if (cnt < XPOS_MAX && p < 128u) w |= p << (7u * cnt);
+        cnt++;
+      }
+    }
+    w |= (cnt > 15u ? 15u : cnt) << 28;
+  }
+  xpos[i] = w;
+}
+
+// *bad = 1 if some read holds more than XPOS_MAX X and that many mismatches are within its budget
+__global__ void k_xpos_check(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ xpos, uint64_t nreads, int rw,
+                             const uint16_t* __restrict__ nmiss_tab, uint32_t max_len, uint32_t* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  const uint32_t cnt = XPOS_CNT(xpos[i]);
+  if (cnt <= XPOS_MAX) return;
+  const uint32_t len = rd[(i + 1) * rw - 1] & 0xFFFFu;
+  const uint32_t budget = len <= max_len ? nmiss_tab[len] : 0xFFFFu;
+  if (cnt == 15u || cnt <= budget) atomicOr(bad, 1u);
+}
+
+template <int RW, bool W2, bool RX>
 __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                      const MatchParams* __restrict__ mp,
                                                      const uint16_t* __restrict__ nmiss_tab,
@@ -58,7 +102,8 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
                                                      unsigned long long* __restrict__ counters,
                                                      const uint4* __restrict__ pstage, const uint32_t* __restrict__ ptcount2,
                                                      const uint32_t* __restrict__ ptpre, uint32_t pnwt,
-                                                     uint4* __restrict__ hits, uint64_t hits_cap) {
+                                                     uint4* __restrict__ hits, uint64_t hits_cap,
+                                                     const uint32_t* __restrict__ rdx) {
   constexpr int WMAX = W2 ? 2 : CTX_MAX_W;
   constexpr int NWAVE = TILE / 64;
   constexpr int RPAD = 8;  // words in front of and behind a wave's records that a shifted window may touch
@@ -74,6 +119,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
   __shared__ uint32_t s_oix[NWAVE][MATCH_DOWN];           // overflow step: flat item -> index within its bucket's overflow list
   __shared__ uint8_t s_own[NWAVE][MATCH_DOWN];            //                flat item -> read slot
   __shared__ uint16_t s_nm[CONF_NM];
+  __shared__ uint32_t s_xp[RX ? NWAVE : 1][RX ? WT : 1];  // RX: the reads' xpos words (1 KB: what the 2 KB LDS granule leaves free)
 
   const int W = mp->W, ww = mp->ww, CL = mp->CL;
   const int win0 = mp->win[0], win1 = mp->win[1];
@@ -111,20 +157,34 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
     const uint32_t i = wt * WT + (opaque(threadIdx.x) & 63);
     rec.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);
   };
-  auto phase_a1 = [&](uint32_t wt, uint32_t par, const Rec<RW>& rec) -> uint32_t {
+  auto phase_a1 = [&](uint32_t wt, uint32_t par, const Rec<RW>& rec, uint32_t& xw) -> uint32_t {
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6;
     uint32_t* const bb_l = s_bb[par][wid];
     const bool active = wt * WT + lane < n;
     const int len = (int)rec.len();
     uint32_t valid = 0;
+    // RX: windows that hold an X never probe; a read with more X than fit the word has no tuples
+    xw = 0;
+    uint32_t xwin = 0;  // windows barred by an X
+    if constexpr (RX) {
+      if (active && rec.has_x()) xw = rdx[r0 + wt * WT + lane];
+      const uint32_t xc = XPOS_CNT(xw);
+      if (xc > XPOS_MAX) xwin = 0xFFFFFFFFu;
+      for (int k = 0; k < W; k++) {
+        const uint32_t q1 = (uint32_t)mp->win[k];
+#pragma unroll
+        for (int q = 0; q < XPOS_MAX; q++)
+          if ((uint32_t)q < xc && XPOS_AT(xw, q) - q1 < (uint32_t)ww) xwin |= 1u << k;
+      }
+    }
     if (ww <= 16 && mp->direct) {
       // the usual case: the window key is one 32-bit word
       const uint32_t kmask = ww == 16 ? 0xFFFFFFFFu : ((1u << (2 * ww)) - 1u);
       for (int k = 0; k < W; k++) {
         const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
         const uint32_t key = (uint32_t)rec.ext(2 * q1) & kmask;
-        bool pt = active && (uint32_t)len >= q2;
+        bool pt = active && (uint32_t)len >= q2 && !((xwin >> k) & 1u);
         if (mp->min_dinuc > 0) pt = pt && key_count_dinuc16(key, ww) >= mp->min_dinuc;
         bb_l[k * WT + lane] = pt ? __brev(key) >> (32 - 2 * ww) : WB_NONE;
         valid |= pt ? 1u << k : 0u;
@@ -134,7 +194,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
         uint32_t b = WB_NONE;
         const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
         if (active) {
-          bool pt = (uint32_t)len >= q2;
+          bool pt = (uint32_t)len >= q2 && !((xwin >> k) & 1u);
           if (pt && mp->min_dinuc > 0)
             pt = (ww <= 16 ? rec_count_dinuc16(rec, q1, ww) : rec_count_dinuc(rec, rec, false, q1, ww)) >= mp->min_dinuc;
           if (pt) {
@@ -149,9 +209,10 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
     return valid;
   };
   // returns the tile's common read length or ~0
-  auto phase_a2 = [&](uint32_t wt, const Rec<RW>& rec, uint32_t valid) -> uint32_t {
+  auto phase_a2 = [&](uint32_t wt, const Rec<RW>& rec, uint32_t valid, uint32_t xw) -> uint32_t {
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6;
+    if constexpr (RX) s_xp[wid][lane] = xw;
     uint32_t* const wcnt_l = s_dyn + wid * WT * W;
     const bool active = wt * WT + lane < n;
     const int len = (int)rec.len();
@@ -223,8 +284,9 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
   if (gw < nwt) {
     Rec<RW> rec;
     fetch(gw, rec);
-    const uint32_t valid = phase_a1(gw, 0, rec);
-    ulen = phase_a2(gw, rec, valid);
+    uint32_t xw;
+    const uint32_t valid = phase_a1(gw, 0, rec, xw);
+    ulen = phase_a2(gw, rec, valid, xw);
     wave_lds_sync();
 #pragma unroll
     for (int rr = 0; rr < MATCH_RING; rr++) issue(0, 0, rr, va[rr], vb[rr]);
@@ -248,6 +310,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
     const bool have_next = wt + nw < nwt;
     Rec<RW> nrec;              // the next wave-tile's records, from a1 to a2
     uint32_t nvalid_next = 0;  // and its valid-window masks
+    uint32_t nxw = 0;          // and (RX) its xpos words
     uint32_t nlist = 0;  // reported candidates of this wave-tile so far (wave-uniform)
     uint32_t qn = 0;     // entries on the stack (wave-uniform)
 
@@ -331,7 +394,22 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
         for (int j = 0; j < 8; j++) img[j] = bs ? __builtin_amdgcn_alignbit(x[j + 1], x[j], 32u - bs) : x[j + 1];
         c[7] &= 0xFFFFu;
         const uint32_t exact0 = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
-        w = ctx_score<ULEN>(img, c, sh, k, mp, W, exact0, REC_BUDGET(meta), ri, ULEN ? ulen : (uint32_t)rlen, lm);
+        uint32_t xm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (RX) {
+          // the read's X in the image's coordinates (only passes that hold such a read pay for it)
+          const uint32_t xw = s_xp[wid][ri];
+          if (__any(xw != 0)) {
+            const uint32_t xc = XPOS_CNT(xw);
+#pragma unroll
+            for (int q = 0; q < XPOS_MAX; q++) {
+              const uint32_t b = sh + 2u * XPOS_AT(xw, q);
+              const uint32_t bit = (uint32_t)q < xc ? 1u << (b & 31u) : 0u;
+#pragma unroll
+              for (int j = 0; j < 8; j++) xm[j] |= (b >> 5) == (uint32_t)j ? bit : 0u;
+            }
+          }
+        }
+        w = ctx_score<ULEN, RX>(img, c, sh, k, mp, W, exact0, REC_BUDGET(meta), ri, ULEN ? ulen : (uint32_t)rlen, lm, xm);
       }
       report(w, gene, jx - (uint32_t)q1);
     };
@@ -354,7 +432,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
           // arrival steps can refill the ring with the next tile's first steps
           if (k + 1 == W && have_next) {
             fetch(wt + nw, nrec);
-            nvalid_next = phase_a1(wt + nw, par ^ 1u, nrec);
+            nvalid_next = phase_a1(wt + nw, par ^ 1u, nrec, nxw);
             wave_lds_sync();
           }
 #pragma unroll
@@ -432,7 +510,7 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
       // the next wave-tile's records and meta words take the place of this one's (its first bucket
       // lines have been on their way since this tile's last window)
       uint32_t ulen_next = 0xFFFFFFFFu;
-      if (have_next) ulen_next = phase_a2(wt + nw, nrec, nvalid_next);
+      if (have_next) ulen_next = phase_a2(wt + nw, nrec, nvalid_next, nxw);
       pcopy_end(cpv, cpm, cpd);
       cnt_l[lane] = 0;  // the stack becomes cnt / base
       wave_lds_sync();

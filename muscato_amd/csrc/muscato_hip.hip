@@ -127,6 +127,14 @@ struct musc_ctx {
   uint32_t* dbm2 = nullptr;  // null when the database holds no X (or an all-zero plane made for reads that do)
   bool db_has_x = false;     // the database holds an X
   bool reads_have_x = false; // some loaded read holds an X
+  // reads with X on context buckets (k_match_d<.., RX>): where each read's X are (k_read_xpos), and
+  // whether the reads in hand fit that form under a given mismatch budget (k_xpos_check), cached
+  DevBuf<uint32_t> rdx;
+  uint64_t rdx_epoch = ~0ull;
+  uint64_t xok_epoch = ~0ull;
+  double xok_pmatch = -1.0;
+  int32_t xok_mmp1 = -1;
+  bool xok = false;
   uint32_t* dbx = nullptr;   // with dbm2: one bit per 64-base block that holds an X
   uint64_t* seq_off = nullptr;
   uint32_t nseq = 0;
@@ -527,7 +535,7 @@ void musc_destroy(musc_ctx* c) {
     c->bs[i].wb.release(); c->bs[i].tbase.release(); c->bs[i].rvalid.release(); c->bs[i].tcount.release();
     c->bs[i].cdesc.release();
   }
-  c->scan_tmp.release(); c->tcount2.release(); c->tpre.release(); c->stage.release();
+  c->scan_tmp.release(); c->tcount2.release(); c->tpre.release(); c->stage.release(); c->rdx.release();
   c->tcount2_b.release(); c->tpre_b.release(); c->stage_b.release();
   c->p_nx.release();
   c->nmiss_tab.release();
@@ -862,13 +870,67 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
 // Which index a run with these parameters and reads of at most max_len bases uses: context
 // buckets when every read fits their 120 bases of context around each of at most CTX_MAX_W
 // windows, nothing holds an X (the context has no mask plane) and positions fit 32 bits.
+// Which of the two kernels on context buckets runs: k_match_d (dense comparison passes,
+// kernels_match_dense.hpp) where its LDS budget allows three workgroups per CU -- at most two
+// windows and records of at most eight words -- and k_match (comparison where the line arrives)
+// otherwise.  MUSC_MATCH=quad forces k_match.
+static bool match_dense(const musc_ctx* c, int W) {
+  const char* e = getenv("MUSC_MATCH");
+  if (e && !strcmp(e, "quad")) return false;
+  return W <= 2 && c->rw <= 8;
+}
+
+// Reads with X fit the context path if every read that holds more than XPOS_MAX of them could not
+// match anyway (that many mismatches exceed its budget int((1 - PMatch) * len)).  One small kernel
+// and a 4-byte readback per (read set, PMatch, MaxMismatch).
+static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
+  if (!c->rdm || !c->rd || !c->nreads) return false;
+  if (getenv("MUSC_NO_X_CONTEXT")) return false;
+  if (c->rdx_epoch != c->data_epoch) {
+    if (ensure(c, c->rdx, c->nreads)) return false;
+    hipLaunchKernelGGL(k_read_xpos, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
+    if (hipGetLastError() != hipSuccess) return false;
+    c->rdx_epoch = c->data_epoch;
+    c->xok_epoch = ~0ull;
+  }
+  if (c->xok_epoch == c->data_epoch && c->xok_pmatch == P->pmatch && c->xok_mmp1 == P->max_mismatch_p1) return c->xok;
+  std::vector<uint16_t> tab((size_t)max_len + 2);
+  for (uint32_t L = 0; L < tab.size(); L++) {  // the budget exactly as musc_match_device builds it
+    volatile double a = 1.0 - P->pmatch;
+    volatile double b = a * (double)L;
+    long long v = (long long)b;
+    if (P->max_mismatch_p1 > 0) v = P->max_mismatch_p1 - 1;
+    if (v < 0) v = 0;
+    if (v > 0xFFFE) v = 0xFFFE;
+    tab[L] = (uint16_t)v;
+  }
+  TmpBufs B;
+  uint16_t* d_tab = nullptr;
+  uint32_t bad = 1;
+  if (B.alloc(&d_tab, tab.size() * 2) != hipSuccess) return false;
+  if (hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
+  if (hipMemsetAsync(c->d_flag, 0, 4, c->stream) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_xpos_check, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdx.p, c->nreads, c->rw, d_tab,
+                     max_len, c->d_flag);
+  if (hipMemcpyAsync(&bad, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+  c->xok = bad == 0;
+  c->xok_epoch = c->data_epoch;
+  c->xok_pmatch = P->pmatch;
+  c->xok_mmp1 = P->max_mismatch_p1;
+  return c->xok;
+}
+
 static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL) {
   if (const char* e = getenv("MUSC_INDEX"))
     if (strcmp(e, "classic") == 0) return false;
   // (the planes themselves may exist without an X: an all-zero one is made for the side that has
   // none when the other side does, and the database's stays for the context's lifetime)
-  if (c->db_has_x || c->reads_have_x) return false;
+  if (c->db_has_x) return false;
   if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
+  // reads with X: only k_match_d handles them, and only while every read either lists all its X in
+  // its xpos word or has more X than mismatches allowed (reads_x_fit, cached per reads + budget)
+  if (c->reads_have_x && !(match_dense(c, P->n_windows) && reads_x_fit(c, P, max_len))) return false;
   if (P->n_windows > CTX_MAX_W) return false;
   int q1min = P->windows[0], q1max = P->windows[0];
   for (int k = 1; k < P->n_windows; k++) {
@@ -1008,16 +1070,6 @@ static size_t match_dyn_lds(int W, int block_mode) {
   return block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;  // TILE = 4 waves x 64
 }
 
-// Which of the two kernels on context buckets runs: k_match_d (dense comparison passes,
-// kernels_match_dense.hpp) where its LDS budget allows three workgroups per CU -- at most two
-// windows and records of at most eight words -- and k_match (comparison where the line arrives)
-// otherwise.  MUSC_MATCH=quad forces k_match.
-static bool match_dense(const musc_ctx* c, int W) {
-  const char* e = getenv("MUSC_MATCH");
-  if (e && !strcmp(e, "quad")) return false;
-  return W <= 2 && c->rw <= 8;
-}
-
 // workgroups of the kernel that are resident at once on this device: the persistent grid
 template <int RW>
 static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
@@ -1025,7 +1077,9 @@ static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
   const size_t lds = match_dyn_lds(W, block_mode);
   hipError_t e;
   if constexpr (RW <= 8) {
-    if (match_dense(c, W)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match_d<RW, true>, TILE, lds);
+    if (match_dense(c, W))
+      e = c->reads_have_x ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match_d<RW, true, true>, TILE, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match_d<RW, true, false>, TILE, lds);
     else e = w2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, true>, TILE, lds)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, false>, TILE, lds);
   } else {
@@ -1041,7 +1095,9 @@ static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
     hipFuncAttributes fa;
     const void* fn = nullptr;
     if constexpr (RW <= 8) {
-      if (match_dense(c, W)) fn = reinterpret_cast<const void*>(&k_match_d<RW, true>);
+      if (match_dense(c, W))
+        fn = c->reads_have_x ? reinterpret_cast<const void*>(&k_match_d<RW, true, true>)
+                             : reinterpret_cast<const void*>(&k_match_d<RW, true, false>);
     }
     if (!fn) fn = w2 ? reinterpret_cast<const void*>(&k_match<RW, true>) : reinterpret_cast<const void*>(&k_match<RW, false>);
     if (hipFuncGetAttributes(&fa, fn) == hipSuccess) {
@@ -1074,7 +1130,12 @@ static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, i
       const uint4* pst = prev_tiles ? (set ? c->stage.p : c->stage_b.p) : nullptr;
       const uint32_t* ptc = set ? c->tcount2.p : c->tcount2_b.p;
       const uint32_t* ptp = set ? c->tpre.p : c->tpre_b.p;
-      MUSC_LAUNCH_MATCH((k_match_d<RW, true>), pst, ptc, ptp, prev_tiles, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap);
+      if (c->reads_have_x)
+        MUSC_LAUNCH_MATCH((k_match_d<RW, true, true>), pst, ptc, ptp, prev_tiles, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap,
+                          (const uint32_t*)c->rdx.p);
+      else
+        MUSC_LAUNCH_MATCH((k_match_d<RW, true, false>), pst, ptc, ptp, prev_tiles, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap,
+                          (const uint32_t*)nullptr);
       return;
     }
   }

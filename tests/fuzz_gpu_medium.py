@@ -18,6 +18,12 @@ from oracle import muscato_oracle as orc
 from muscato_amd import Config, Engine, sorted_hits
 
 
+# MUSC_FUZZ_READS_X=1: X in the reads only (an X-free database: with at most two windows and reads
+# of at most 112 bases those runs take k_match_d's RX path whenever every read's X fit its xpos word)
+READS_X_ONLY = bool(os.environ.get("MUSC_FUZZ_READS_X"))
+KINDS = {0: 0, 1: 0}
+
+
 def case(seed):
     rng = np.random.default_rng(seed)
     L = int(rng.choice([40, 60, 100, 120, 150]))
@@ -37,7 +43,7 @@ def case(seed):
     T[nt - ncopy:] = T[rng.integers(0, nt - ncopy, size=ncopy)]
     sub = rng.random((ncopy, tlen)) < 0.03
     T[nt - ncopy:][sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
-    if xrate:
+    if xrate and not READS_X_ONLY:
         T[rng.random(T.shape) < xrate] = ord("X")
     g = rng.integers(0, nt, size=nr)
     p = rng.integers(0, tlen - L + 1, size=nr)
@@ -46,6 +52,8 @@ def case(seed):
     R = T[g[:, None], p[:, None] + np.arange(L)[None, :]].copy()
     sub = rng.random(R.shape) < float(rng.choice([0.0, 0.01, 0.03]))
     R[sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    if READS_X_ONLY:  # X (N in the FASTQ) in the reads alone, at rates where most reads keep a few of them
+        xrate = float(rng.choice([0.002, 0.005, 0.02]))
     if xrate:
         R[rng.random(R.shape) < xrate] = ord("X")
     lens = rng.integers(max(ww, L // 2), L + 1, size=nr)
@@ -71,12 +79,14 @@ def main():
         best = sorted_hits(e.match(k, apply_mmtol=True))
         eb = np.array(sorted(orc.best_filter([tuple(int(x) for x in r) for r in exp], c.MMTol)), dtype=np.uint32).reshape(-1, 4)
         ok = ok and best.shape == eb.shape and bool((best == eb).all()) and e.stats()["n_overflow_blocks"] == 0
+        KINDS[e.stats()["index_kind"]] += 1
         if not ok:
             bad += 1
             print("MISMATCH seed", seed, c, len(reads), len(targets), len(got), len(exp), flush=True)
         if seed % 50 == 0:
             print("seed", seed, "hits", len(exp), "elapsed %.0fs" % (time.time() - t0), flush=True)
-    print("fuzz_medium", lo, hi, "bad", bad, "in %.0fs" % (time.time() - t0))
+    print("fuzz_medium", lo, hi, "bad", bad, "in %.0fs" % (time.time() - t0), "index kinds used", KINDS,
+          "(reads-only X)" if READS_X_ONLY else "")
 
 
 if __name__ == "__main__":

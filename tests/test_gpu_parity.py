@@ -627,3 +627,53 @@ def test_batches_of_heavy_tiles_move_their_tuples_in_the_next_launch(monkeypatch
                     assert st["index_kind"] == 1 and st["n_batches"] == -(-len(reads) // int(batch))
                     assert (np.diff(raw[:, 0].astype(np.int64)) >= 0).all(), "the hit list is not read-major"
                     assert_same(sorted_hits(raw), exp)
+
+
+def _x_in_reads_only(seed, n_targets, n_reads, xrate, heavy):
+    """synthetic_medium with X (the reference's letter for N) in the reads alone: `xrate` per base,
+    and `heavy` reads with five to nine X each."""
+    reads, targets = synthetic_medium(seed, n_targets, n_reads)
+    rng = np.random.default_rng(seed + 1)
+    R = np.array([np.frombuffer(r, dtype=np.uint8) for r in reads]).copy()
+    R[rng.random(R.shape) < xrate] = ord("X")
+    for i in rng.choice(len(R), size=heavy, replace=False):
+        R[i, rng.choice(R.shape[1], size=int(rng.integers(5, 10)), replace=False)] = ord("X")
+    return sorted({bytes(r) for r in R}), targets
+
+
+@pytest.mark.parametrize("pmatch,ww,windows,fits", [(0.97, 15, (0, 20), True), (0.96, 12, (0, 20), True), (0.95, 15, (3, 20), False),
+                                                    (0.97, 17, (0, 20), True)])
+def test_reads_with_x_against_an_x_free_database(eng, pmatch, ww, windows, fits):
+    """Reads with X (N in the FASTQ) against a database without any: on context buckets k_match_d
+    treats an X as a mismatch wherever the read lands and keeps windows that hold one from probing
+    (kernels_match_dense.hpp, RX).  A read with more X than its xpos word lists takes part only
+    if that many mismatches exceed its budget: 100 bp at PMatch 0.97 / 0.96 allows 3 / 4 < 5..9, at
+    0.95 it allows 5 and the run takes the two-kernel path.  Tuples against the literal oracle."""
+    from muscato_amd import sorted_hits
+    reads, targets = _x_in_reads_only(500 + ww, 3000, 40000, 0.004, 300)
+    c = orc.Config(Windows=list(windows), WindowWidth=ww, PMatch=pmatch, MinDinuc=3, MaxReadLength=100,
+                   MaxMatches=1000000, MMTol=1)
+    rbuf, roff = literal.concat(reads)
+    gbuf, goff = literal.concat(targets)
+    exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff,
+                                     literal.make_params(c, bloom_size=128_000_000, num_hash=8, nthreads=8))
+    got = gpu_hits(eng, c, reads, targets, False)
+    st = eng.stats()
+    assert st["index_kind"] == (1 if fits and eng.index_mode == "auto" else 0)
+    assert len(got) > 8000
+    assert_same(got, exp)
+    best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
+    assert_same(best, as_arr(orc.best_filter([tuple(int(x) for x in r) for r in exp], c.MMTol)))
+
+
+@pytest.mark.parametrize("seed", list(range(0, 60, 3)))
+def test_random_cases_with_x_in_the_reads_only(eng, seed):
+    """The X-alphabet cases of make_case with the targets' X replaced: ragged lengths, pos-0, target
+    ends, one to three windows -- reads with X on whichever path the library picks."""
+    ocfg, reads, targets = make_case(seed)
+    targets = [t.replace(b"X", b"A") for t in targets]
+    full = orc.match_direct(reads, targets, ocfg)
+    assert_same(gpu_hits(eng, ocfg, reads, targets, False), as_arr(full))
+    from muscato_amd import sorted_hits
+    got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=True))
+    assert_same(got, as_arr(orc.best_filter(full, ocfg.MMTol)))
