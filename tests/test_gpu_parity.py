@@ -498,9 +498,10 @@ def test_block_screening_falls_back_to_exact_counters(eng):
 
 
 def test_index_selection(monkeypatch):
-    """Which index a run gets (ensure_index): context buckets + the fused k_match when every read
-    fits 120 bases of context around each of at most four windows and nothing holds an X; the
-    64-byte buckets and k_screen -> k_confirm otherwise -- with identical tuples either way."""
+    """Which index a run gets (ensure_index): context buckets + the fused kernel when every read
+    fits 120 bases of context around each of at most four windows and the database holds no X (reads
+    may, where k_match_d runs); the 64-byte buckets and k_screen -> k_confirm otherwise -- with
+    identical tuples either way."""
     from muscato_amd import Config, Engine, sorted_hits
     monkeypatch.delenv("MUSC_INDEX", raising=False)
     rng = random.Random(2)
@@ -519,7 +520,8 @@ def test_index_selection(monkeypatch):
         ("one base too many", [0, 21], 100, b"ACGT", 0),
         ("four windows, 90 bp", [0, 10, 20, 30], 90, b"ACGT", 1),
         ("five windows", [0, 5, 10, 15, 20], 90, b"ACGT", 0),
-        ("reads with X", [0, 20], 100, b"ACGTX", 0),
+        ("reads with X, database without: k_match_d's RX form", [0, 20], 100, b"ACGTX", 1),
+        ("reads with X, three windows: k_match has no RX form", [0, 10, 20], 100, b"ACGTX", 0),
         ("long reads", [0, 20], 150, b"ACGT", 0),
     ]
     with Engine(0) as eng:
@@ -531,6 +533,16 @@ def test_index_selection(monkeypatch):
             got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
             assert eng.stats()["index_kind"] == kind, what
             assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
+        # a database with X: the two-kernel path
+        eng.load_targets([t[:50] + b"X" + t[51:] for t in targets[:3]] + targets[3:])
+        reads = reads_of(100)
+        ocfg = orc.Config(Windows=[0, 20], WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=100, MaxMatches=100000)
+        eng.load_reads(reads)
+        got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+        assert eng.stats()["index_kind"] == 0
+        xt = [t[:50] + b"X" + t[51:] for t in targets[:3]] + targets[3:]
+        assert_same(got, as_arr(orc.match_direct(reads, xt, ocfg)))
+        eng.load_targets(targets)
         # forced
         monkeypatch.setenv("MUSC_INDEX", "classic")
         reads = reads_of(100)
