@@ -112,10 +112,11 @@ typedef struct {
                              * 0 with context buckets (no descriptors exist)               */
   /* ---- since ABI version 2 */
   uint32_t index_kind;      /* index the pass ran on: 0 = 64-byte buckets + target gather
-                             * (k_screen -> k_confirm), 1 = context buckets (k_match)       */
-  uint32_t match_launches;  /* k_match launches (index_kind 1)                              */
+                             * (k_screen -> k_confirm), 1 = context buckets (k_match_d or
+                             * k_match)                                                     */
+  uint32_t match_launches;  /* launches of that kernel (index_kind 1)                       */
   uint64_t n_overflow_entries; /* index entries beyond a bucket's inline ones that were walked */
-  uint64_t match_bytes;     /* algorithmic bytes of the k_match launches: record (ceil(2L/8) B)
+  uint64_t match_bytes;     /* algorithmic bytes of those launches: record (ceil(2L/8) B)
                              * per read + one 128-B bucket line per probe + 40 B per overflow
                              * entry walked + 16 B per tuple staged                         */
   uint64_t match_bytes_strict; /* the same with a probe billed for what it uses of its line:

@@ -867,9 +867,6 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
   return 0;
 }
 
-// Which index a run with these parameters and reads of at most max_len bases uses: context
-// buckets when every read fits their 120 bases of context around each of at most CTX_MAX_W
-// windows, nothing holds an X (the context has no mask plane) and positions fit 32 bits.
 // Which of the two kernels on context buckets runs: k_match_d (dense comparison passes,
 // kernels_match_dense.hpp) where its LDS budget allows three workgroups per CU -- at most two
 // windows and records of at most eight words -- and k_match (comparison where the line arrives)
@@ -921,6 +918,10 @@ static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
   return c->xok;
 }
 
+// Which index a run with these parameters and reads of at most max_len bases uses: context
+// buckets when every read fits their 120 bases of context around each of at most CTX_MAX_W
+// windows, the database holds no X (the context has no mask plane; reads may hold some where
+// k_match_d runs, see reads_x_fit) and positions fit 32 bits.
 static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL) {
   if (const char* e = getenv("MUSC_INDEX"))
     if (strcmp(e, "classic") == 0) return false;
