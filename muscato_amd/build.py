@@ -4,13 +4,19 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmuscato_hip.so")
-SOURCES = [os.path.join(CSRC, "muscato_hip.hip")]
+OBJ = os.path.join(HERE, "build")
+# one translation unit for the host side and most kernels, and one per record stride for k_match_t
+# (kernels_match_lane_inst.hpp): they compile side by side
+SOURCES = [os.path.join(CSRC, f) for f in ("muscato_hip.hip", "match_lane_rw4.hip", "match_lane_rw8.hip", "match_lane_rw12.hip")]
 HEADERS = [os.path.join(os.path.dirname(HERE), "include", "muscato_hip.h")] + \
     [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
+LANE_ONLY = os.path.join(CSRC, "kernels_match_lane.hpp")  # k_match_t's definition: muscato_hip.hip sees its declaration only
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:
@@ -52,10 +58,24 @@ def build_tools(force: bool = False, verbose: bool = False) -> None:
         subprocess.check_call(cmd)
 
 
+def _compile(src: str, force: bool, verbose: bool, defines=(), tag: str = "") -> str:
+    obj = os.path.join(OBJ, os.path.basename(src) + tag + ".o")
+    deps = [src] + [h for h in HEADERS if h != LANE_ONLY or "match_lane" in os.path.basename(src)]
+    if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+        return obj
+    cmd = [hipcc()] + FLAGS + list(defines) + ["-c", "-o", obj, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES + ["-ldl"]
+        os.makedirs(OBJ, exist_ok=True)
+        with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+            objs = list(ex.map(lambda s: _compile(s, force, verbose), SOURCES))
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -63,5 +83,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def variant(name: str, defines) -> str:
+    """A library whose k_match_t units are compiled with extra -D flags (tuning sessions:
+    build_variants/<name>.so, run with MUSC_LIB_PATH); the main unit's object is shared."""
+    os.makedirs(OBJ, exist_ok=True)
+    out_dir = os.path.join(os.path.dirname(HERE), "build_variants")
+    os.makedirs(out_dir, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, False, False, defines if "match_lane" in s else (), "." + name if "match_lane" in s else ""), SOURCES))
+    out = os.path.join(out_dir, name + ".so")
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "variant":
+        print(variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -7,6 +7,12 @@
 // ------------------------------------------------------------------------------------
 
 #define DEV __device__ __forceinline__
+// Kernels that are not templates: defined once, in muscato_hip.hip.  The translation units that hold
+// only k_match_t (match_lane_rw*.hip) include the same headers with MUSC_KERNEL = a static kernel
+// nobody launches, which the compiler then drops.
+#ifndef MUSC_KERNEL
+#define MUSC_KERNEL __global__
+#endif
 #define READ_HAS_X 0x10000u  // length word of a read record, bit 16: the read holds an X
 
 DEV uint64_t mix64(uint64_t x) {
@@ -82,7 +88,7 @@ DEV uint32_t ascii_code(unsigned char c, uint32_t* isx) {
 }
 
 // one thread per u32 word (16 bases) of the database stream
-__global__ void k_pack_db_ascii(const unsigned char* __restrict__ s, uint64_t nbases,
+MUSC_KERNEL void k_pack_db_ascii(const unsigned char* __restrict__ s, uint64_t nbases,
                                 uint32_t* __restrict__ db2, uint32_t* __restrict__ dbm2,
                                 uint64_t nwords, uint32_t* __restrict__ has_x) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,7 +110,7 @@ __global__ void k_pack_db_ascii(const unsigned char* __restrict__ s, uint64_t nb
 }
 
 // 2-bit stream + optional 1-bit mask (ABI packed form) -> internal planes
-__global__ void k_pack_db_packed(const uint32_t* __restrict__ in2, const uint16_t* __restrict__ inm,
+MUSC_KERNEL void k_pack_db_packed(const uint32_t* __restrict__ in2, const uint16_t* __restrict__ inm,
                                  uint32_t* __restrict__ db2, uint32_t* __restrict__ dbm2,
                                  uint64_t nwords, uint32_t* __restrict__ has_x) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,7 +128,7 @@ __global__ void k_pack_db_packed(const uint32_t* __restrict__ in2, const uint16_
 // dbx: one bit per block of 64 database bases (4 words of the mask plane), set when the block
 // holds an X.  2 MB per Gbp: stays in L2, so k_confirm gathers the mask plane only for the few
 // spans that need it.
-__global__ void k_db_xblocks(const uint32_t* __restrict__ dbm2, uint64_t nwords, uint32_t* __restrict__ dbx) {
+MUSC_KERNEL void k_db_xblocks(const uint32_t* __restrict__ dbm2, uint64_t nwords, uint32_t* __restrict__ dbx) {
   const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (blk * 4 >= nwords) return;
   uint32_t any = 0;
@@ -138,7 +144,7 @@ DEV bool db_span_has_x(const uint32_t* __restrict__ dbx, uint64_t gpos, uint32_t
   return ((w >> (b0 & 31)) & (nb >= 32 ? 0xFFFFFFFFull : ((1ull << nb) - 1ull))) != 0;
 }
 
-__global__ void k_max_len(const uint64_t* __restrict__ off, uint64_t n, unsigned long long* out) {
+MUSC_KERNEL void k_max_len(const uint64_t* __restrict__ off, uint64_t n, unsigned long long* out) {
   __shared__ unsigned long long s_m[16];
   unsigned long long l = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block(const uint32_t* __res
   if (block_sums && threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ out,
+MUSC_KERNEL __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ out,
                                                         const uint32_t* __restrict__ block_off,
                                                         uint64_t n) {
   const uint32_t add = block_off[blockIdx.x];
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ 
 
 // u64 variant of the scan for the overflow-list offsets of big databases (index build only;
 // plain element accesses, no tuning needed)
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan64_block(const uint64_t* __restrict__ in,
+MUSC_KERNEL __launch_bounds__(SCAN_BLOCK) void k_scan64_block(const uint64_t* __restrict__ in,
                                                             uint64_t* __restrict__ out,
                                                             uint64_t* __restrict__ block_sums, uint64_t n) {
   __shared__ uint64_t s_wave[SCAN_BLOCK / 64];
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan64_block(const uint64_t* __r
   if (block_sums && threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan64_add(uint64_t* __restrict__ out,
+MUSC_KERNEL __launch_bounds__(SCAN_BLOCK) void k_scan64_add(uint64_t* __restrict__ out,
                                                           const uint64_t* __restrict__ block_off, uint64_t n) {
   const uint64_t add = block_off[blockIdx.x];
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void
 
 // k_compact -- hits[counters[2] + tpre[tile] ...] = the tile's staged tuples (tpre = scan of
 // tcount2): plain 16-byte copies, a tile's run is contiguous on both sides.
-__global__ __launch_bounds__(256) void k_compact(uint32_t ntiles, const uint32_t* __restrict__ tbase,
+MUSC_KERNEL __launch_bounds__(256) void k_compact(uint32_t ntiles, const uint32_t* __restrict__ tbase,
                                                  const uint32_t* __restrict__ tcount2,
                                                  const uint32_t* __restrict__ tpre,
                                                  const uint4* __restrict__ stage, uint4* __restrict__ hits,
@@ -386,13 +386,13 @@ __global__ __launch_bounds__(256) void k_hot_probes(const uint32_t* __restrict__
 }
 
 // counters[2] (hits so far) += tpre[ntiles] (hits of this batch)
-__global__ void k_advance(const uint32_t* __restrict__ tpre, uint32_t ntiles, unsigned long long* counters) {
+MUSC_KERNEL void k_advance(const uint32_t* __restrict__ tpre, uint32_t ntiles, unsigned long long* counters) {
   if (threadIdx.x == 0 && blockIdx.x == 0) counters[2] += tpre[ntiles];
 }
 
 // number of block counters above MaxMatches (hash collisions only inflate counters, so 0 is
 // a proof that no window-key block overflowed)
-__global__ void k_block_overflow(const uint32_t* __restrict__ block_table, uint32_t max_matches,
+MUSC_KERNEL void k_block_overflow(const uint32_t* __restrict__ block_table, uint32_t max_matches,
                                  unsigned long long* __restrict__ counters) {
   unsigned long long c = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (1u << BLOCK_TABLE_BITS); i += gridDim.x * blockDim.x)
@@ -407,7 +407,7 @@ struct PackBits {
   int32_t read, gene, pos, nmiss;
 };
 
-__global__ __launch_bounds__(256) void k_pack_hits(const uint4* __restrict__ hits, uint64_t n, uint64_t read_base,
+MUSC_KERNEL __launch_bounds__(256) void k_pack_hits(const uint4* __restrict__ hits, uint64_t n, uint64_t read_base,
                                                    PackBits b, uint64_t* __restrict__ out, uint32_t* __restrict__ bad) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint4 h = hits[i];
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_pack_hits(const uint4* __restrict__ hit
   }
 }
 
-__global__ __launch_bounds__(256) void k_unpack_hits(const uint64_t* __restrict__ in, uint64_t n, PackBits b,
+MUSC_KERNEL __launch_bounds__(256) void k_unpack_hits(const uint64_t* __restrict__ in, uint64_t n, PackBits b,
                                                      uint4* __restrict__ hits) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t v = in[i];
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_unpack_hits(const uint64_t* __restrict_
 // travels as one byte per read -- counts[r] = tuples of read r -- and a tuple is ONE u32 word:
 // gene | pos | nmiss with caller-chosen widths.  *bad: 1 a field does not fit, 2 a read has more
 // than 255 tuples, 4 the list is not read-major (cannot happen; checked because the format rests on it).
-__global__ __launch_bounds__(256) void k_pack_compact(const uint4* __restrict__ hits, uint64_t n, PackBits b,
+MUSC_KERNEL __launch_bounds__(256) void k_pack_compact(const uint4* __restrict__ hits, uint64_t n, PackBits b,
                                                       uint32_t* __restrict__ words, uint8_t* __restrict__ counts,
                                                       uint32_t* __restrict__ bad) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_index(const uint32_t* __restrict__ db2,
 }
 
 // overflow list sizes: tmp[b] = max(count - 3, 0), scanned on the side, written back as ovf
-__global__ void k_index_ovf_count(const Bucket* __restrict__ T, uint64_t nb, uint64_t* __restrict__ tmp) {
+MUSC_KERNEL void k_index_ovf_count(const Bucket* __restrict__ T, uint64_t nb, uint64_t* __restrict__ tmp) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) {
     const uint32_t c = T[b].count;
@@ -91,7 +91,7 @@ __global__ void k_index_ovf_count(const Bucket* __restrict__ T, uint64_t nb, uin
   }
 }
 
-__global__ void k_index_ovf_set(Bucket* __restrict__ T, uint64_t nb, const uint64_t* __restrict__ tmp) {
+MUSC_KERNEL void k_index_ovf_set(Bucket* __restrict__ T, uint64_t nb, const uint64_t* __restrict__ tmp) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) T[b].ovf = tmp[b];
 }

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
   }
 }
 
-__global__ void k_ctx_ovf_count(const CtxBucket* __restrict__ T, uint64_t nb, uint64_t* __restrict__ tmp) {
+MUSC_KERNEL void k_ctx_ovf_count(const CtxBucket* __restrict__ T, uint64_t nb, uint64_t* __restrict__ tmp) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) {
     const uint32_t c = T[b].count;
@@ -124,7 +124,7 @@ __global__ void k_ctx_ovf_count(const CtxBucket* __restrict__ T, uint64_t nb, ui
   }
 }
 
-__global__ void k_ctx_ovf_set(CtxBucket* __restrict__ T, uint64_t nb, const uint64_t* __restrict__ tmp) {
+MUSC_KERNEL void k_ctx_ovf_set(CtxBucket* __restrict__ T, uint64_t nb, const uint64_t* __restrict__ tmp) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) T[b].ovf = (uint32_t)tmp[b];
 }
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
 
 // k_compact_w -- hits[counters[2] + tpre[wt] ...] = the wave-tile's staged tuples (tpre = scan of
 // tcount2), a wave per wave-tile: plain 16-byte copies, contiguous on both sides.
-__global__ __launch_bounds__(256) void k_compact_w(uint32_t nwt, const uint32_t* __restrict__ tbase,
+MUSC_KERNEL __launch_bounds__(256) void k_compact_w(uint32_t nwt, const uint32_t* __restrict__ tbase,
                                                    const uint32_t* __restrict__ tcount2,
                                                    const uint32_t* __restrict__ tpre, const uint4* __restrict__ stage,
                                                    uint4* __restrict__ hits, uint64_t hits_cap,

@@ -55,7 +55,7 @@
 #define XPOS_CNT(w) ((w) >> 28)
 #define XPOS_AT(w, q) (((w) >> (7 * (q))) & 127u)
 
-__global__ void k_read_xpos(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm, uint64_t nreads, int rw,
+MUSC_KERNEL void k_read_xpos(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm, uint64_t nreads, int rw,
                             uint32_t* __restrict__ xpos) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nreads) return;
@@ -78,7 +78,7 @@ __global__ void k_read_xpos(const uint32_t* __restrict__ rd, const uint32_t* __r
 }
 
 // *bad = 1 if some read holds more than XPOS_MAX X and that many mismatches are within its budget
-__global__ void k_xpos_check(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ xpos, uint64_t nreads, int rw,
+MUSC_KERNEL void k_xpos_check(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ xpos, uint64_t nreads, int rw,
                              const uint16_t* __restrict__ nmiss_tab, uint32_t max_len, uint32_t* __restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nreads) return;

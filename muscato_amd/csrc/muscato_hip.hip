@@ -42,6 +42,10 @@
 #include "kernels_confirm.hpp"
 #include "kernels_match.hpp"
 #include "kernels_match_dense.hpp"
+#include "kernels_match_lane_inst.hpp"  // k_match_t: declaration only (defined in match_lane_rw*.hip)
+MUSC_LANE_INSTANCES(extern, 4)
+MUSC_LANE_INSTANCES(extern, 8)
+MUSC_LANE_INSTANCES(extern, 12)
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -867,14 +871,16 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
   return 0;
 }
 
-// Which of the two kernels on context buckets runs: k_match_d (dense comparison passes,
-// kernels_match_dense.hpp) where its LDS budget allows three workgroups per CU -- at most two
-// windows and records of at most eight words -- and k_match (comparison where the line arrives)
-// otherwise.  MUSC_MATCH=quad forces k_match.
-static bool match_dense(const musc_ctx* c, int W) {
+// Which of the kernels on context buckets runs: k_match_t (comparisons in the lane that owns the read,
+// kernels_match_lane.hpp) by default; MUSC_MATCH=dense selects k_match_d (dense comparison passes,
+// kernels_match_dense.hpp: at most two windows, records of at most eight words) and MUSC_MATCH=quad
+// k_match (comparison where the line arrives) -- the two earlier kernels, kept for A/B runs.
+enum MatchKind { MK_QUAD = 0, MK_DENSE = 1, MK_LANE = 2 };
+static int match_kind(const musc_ctx* c, int W) {
   const char* e = getenv("MUSC_MATCH");
-  if (e && !strcmp(e, "quad")) return false;
-  return W <= 2 && c->rw <= 8;
+  if (e && !strcmp(e, "quad")) return MK_QUAD;
+  if (e && !strcmp(e, "dense")) return (W <= 2 && c->rw <= 8) ? MK_DENSE : MK_QUAD;
+  return MK_LANE;
 }
 
 // Reads with X fit the context path if every read that holds more than XPOS_MAX of them could not
@@ -929,9 +935,9 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
   // none when the other side does, and the database's stays for the context's lifetime)
   if (c->db_has_x) return false;
   if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
-  // reads with X: only k_match_d handles them, and only while every read either lists all its X in
-  // its xpos word or has more X than mismatches allowed (reads_x_fit, cached per reads + budget)
-  if (c->reads_have_x && !(match_dense(c, P->n_windows) && reads_x_fit(c, P, max_len))) return false;
+  // reads with X: k_match_t / k_match_d handle them, and only while every read either lists all its X
+  // in its xpos word or has more X than mismatches allowed (reads_x_fit, cached per reads + budget)
+  if (c->reads_have_x && !(match_kind(c, P->n_windows) != MK_QUAD && reads_x_fit(c, P, max_len))) return false;
   if (P->n_windows > CTX_MAX_W) return false;
   int q1min = P->windows[0], q1max = P->windows[0];
   for (int k = 1; k < P->n_windows; k++) {
@@ -1071,22 +1077,35 @@ static size_t match_dyn_lds(int W, int block_mode) {
   return block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;  // TILE = 4 waves x 64
 }
 
+// the kernel a pass launches, as a function pointer (occupancy queries and attributes)
+template <int RW>
+static const void* match_fn(const musc_ctx* c, int W) {
+  const int kind = match_kind(c, W);
+  const bool rx = c->reads_have_x;
+  if (kind == MK_LANE) {
+#define MUSC_LANE_FN(WN) reinterpret_cast<const void*>(&k_match_t<RW, WN>)
+    switch (W) {
+      case 1: return MUSC_LANE_FN(1);
+      case 2: return MUSC_LANE_FN(2);
+      case 3: return MUSC_LANE_FN(3);
+      default: return MUSC_LANE_FN(4);
+    }
+#undef MUSC_LANE_FN
+  }
+  if constexpr (RW <= 8) {
+    if (kind == MK_DENSE)
+      return rx ? reinterpret_cast<const void*>(&k_match_d<RW, true, true>) : reinterpret_cast<const void*>(&k_match_d<RW, true, false>);
+  }
+  return W <= 2 ? reinterpret_cast<const void*>(&k_match<RW, true>) : reinterpret_cast<const void*>(&k_match<RW, false>);
+}
+
 // workgroups of the kernel that are resident at once on this device: the persistent grid
 template <int RW>
-static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
+static unsigned match_resident(musc_ctx* c, int W, int block_mode) {
   int per_cu = 0, ncu = 0;
   const size_t lds = match_dyn_lds(W, block_mode);
-  hipError_t e;
-  if constexpr (RW <= 8) {
-    if (match_dense(c, W))
-      e = c->reads_have_x ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match_d<RW, true, true>, TILE, lds)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match_d<RW, true, false>, TILE, lds);
-    else e = w2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, true>, TILE, lds)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, false>, TILE, lds);
-  } else {
-    e = w2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, true>, TILE, lds)
-           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_match<RW, false>, TILE, lds);
-  }
+  const void* fn = match_fn<RW>(c, W);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TILE, lds);
   if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
   // The occupancy query counts LDS to the byte; the hardware hands it out in larger pieces
   // (measured on gfx950: 3 x 54 208 B did not fit a CU's 160 KB, 3 x 52 160 B did), and a grid one
@@ -1094,13 +1113,6 @@ static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
   // count with 2 KB pieces.
   {
     hipFuncAttributes fa;
-    const void* fn = nullptr;
-    if constexpr (RW <= 8) {
-      if (match_dense(c, W))
-        fn = c->reads_have_x ? reinterpret_cast<const void*>(&k_match_d<RW, true, true>)
-                             : reinterpret_cast<const void*>(&k_match_d<RW, true, false>);
-    }
-    if (!fn) fn = w2 ? reinterpret_cast<const void*>(&k_match<RW, true>) : reinterpret_cast<const void*>(&k_match<RW, false>);
     if (hipFuncGetAttributes(&fa, fn) == hipSuccess) {
       const size_t total = ((size_t)fa.sharedSizeBytes + lds + 2047) / 2048 * 2048;
       const int fit = total ? (int)((160u << 10) / total) : per_cu;
@@ -1116,31 +1128,42 @@ static unsigned match_resident(musc_ctx* c, bool w2, int W, int block_mode) {
 // set: which staging buffers the launch fills (0: stage / tcount2, 1: stage_b / tcount2_b);
 // prev_tiles > 0: the launch also moves the other set's tuples (the previous batch's) into `hits`
 template <int RW>
-static void launch_match(musc_ctx* c, bool w2, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr,
+static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr,
                          unsigned ngrid, int set = 0, uint32_t prev_tiles = 0) {
   const dim3 grid(ngrid), block(TILE);
   const size_t lds = match_dyn_lds(W, block_mode);
   DevBuf<uint4>& st = set ? c->stage_b : c->stage;
   DevBuf<uint32_t>& tc = set ? c->tcount2_b : c->tcount2;
+  const int kind = match_kind(c, W);
 #define MUSC_LAUNCH_MATCH(K, ...)                                                                                 \
   hipLaunchKernelGGL(K, grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,                       \
                      c->ctx_T, c->ctx_E, st.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,          \
                      tc.p, block_mode, block_thr, c->block_table.p, c->counters, ##__VA_ARGS__)
-  if constexpr (RW <= 8) {
-    if (match_dense(c, W)) {
-      const uint4* pst = prev_tiles ? (set ? c->stage.p : c->stage_b.p) : nullptr;
-      const uint32_t* ptc = set ? c->tcount2.p : c->tcount2_b.p;
-      const uint32_t* ptp = set ? c->tpre.p : c->tpre_b.p;
-      if (c->reads_have_x)
-        MUSC_LAUNCH_MATCH((k_match_d<RW, true, true>), pst, ptc, ptp, prev_tiles, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap,
-                          (const uint32_t*)c->rdx.p);
-      else
-        MUSC_LAUNCH_MATCH((k_match_d<RW, true, false>), pst, ptc, ptp, prev_tiles, reinterpret_cast<uint4*>(c->hits.p), c->hits.cap,
-                          (const uint32_t*)nullptr);
+  if (kind != MK_QUAD) {
+    const uint4* pst = prev_tiles ? (set ? c->stage.p : c->stage_b.p) : nullptr;
+    const uint32_t* ptc = set ? c->tcount2.p : c->tcount2_b.p;
+    const uint32_t* ptp = set ? c->tpre.p : c->tpre_b.p;
+    uint4* const hp = reinterpret_cast<uint4*>(c->hits.p);
+    const uint32_t* const rdx = c->reads_have_x ? (const uint32_t*)c->rdx.p : (const uint32_t*)nullptr;
+    if (kind == MK_LANE) {
+#define MUSC_LAUNCH_LANE(WN)                                                                                 \
+      MUSC_LAUNCH_MATCH((k_match_t<RW, WN>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
+      switch (W) {
+        case 1: MUSC_LAUNCH_LANE(1); break;
+        case 2: MUSC_LAUNCH_LANE(2); break;
+        case 3: MUSC_LAUNCH_LANE(3); break;
+        default: MUSC_LAUNCH_LANE(4); break;
+      }
+#undef MUSC_LAUNCH_LANE
+      return;
+    }
+    if constexpr (RW <= 8) {
+      if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_d<RW, true, true>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx);
+      else MUSC_LAUNCH_MATCH((k_match_d<RW, true, false>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx);
       return;
     }
   }
-  if (w2) MUSC_LAUNCH_MATCH((k_match<RW, true>)); else MUSC_LAUNCH_MATCH((k_match<RW, false>));
+  if (W <= 2) MUSC_LAUNCH_MATCH((k_match<RW, true>)); else MUSC_LAUNCH_MATCH((k_match<RW, false>));
 #undef MUSC_LAUNCH_MATCH
 }
 }  // extern "C++"
@@ -1153,9 +1176,9 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
   // the persistent grid = the workgroups that are resident at once (every wave then sees many
   // wave-tiles and the end-of-kernel atomics stay few); the MaxMatches screening threshold is per
   // workgroup-launch, so it follows the grid
-  const unsigned resident = c->rw == 4 ? match_resident<4>(c, pp.W <= 2, pp.W, block_mode)
-                            : c->rw == 8 ? match_resident<8>(c, pp.W <= 2, pp.W, block_mode)
-                                         : match_resident<12>(c, pp.W <= 2, pp.W, block_mode);
+  const unsigned resident = c->rw == 4 ? match_resident<4>(c, pp.W, block_mode)
+                            : c->rw == 8 ? match_resident<8>(c, pp.W, block_mode)
+                                         : match_resident<12>(c, pp.W, block_mode);
   uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * resident), 0x7FFFFFFFull);
   if (block_mode == 1 && block_thr < 2) block_mode = 2;
   if (block_mode == 2 && !c->block_table.p) {
@@ -1192,7 +1215,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
   }
-  const bool fuse_ok = c->rw <= 8 && match_dense(c, pp.W) && !getenv("MUSC_NO_FUSED_COMPACT");
+  const bool fuse_ok = match_kind(c, pp.W) != MK_QUAD && !getenv("MUSC_NO_FUSED_COMPACT");
   if (sized && fuse_ok && c->nreads > bsz) {  // the second staging set (allocated outside any capture)
     if ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
         (rc = ensure(c, c->tpre_b, c->tpre.cap)))
@@ -1253,9 +1276,9 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       {
         Range rg("k_match");
       switch (c->rw) {
-        case 4: launch_match<4>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
-        case 8: launch_match<8>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
-        default: launch_match<12>(c, pp.W <= 2, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid); break;
+        case 4: launch_match<4>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
+        case 8: launch_match<8>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
+        default: launch_match<12>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
       }
       }
       HIPCHK(c, hipGetLastError());

@@ -32,7 +32,7 @@ DEV uint32_t prep_code(unsigned char ch) {
 }
 
 // keys[i] = key word `w` of read perm[i]
-__global__ __launch_bounds__(256) void k_prep_keys(const unsigned char* __restrict__ s,
+MUSC_KERNEL __launch_bounds__(256) void k_prep_keys(const unsigned char* __restrict__ s,
                                                    const uint64_t* __restrict__ off,
                                                    const uint32_t* __restrict__ perm, uint64_t n, uint32_t w,
                                                    uint64_t* __restrict__ keys) {
@@ -51,13 +51,13 @@ __global__ __launch_bounds__(256) void k_prep_keys(const unsigned char* __restri
   }
 }
 
-__global__ void k_prep_iota(uint32_t* __restrict__ p, uint64_t n) {
+MUSC_KERNEL void k_prep_iota(uint32_t* __restrict__ p, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     p[i] = (uint32_t)i;
 }
 
 // head[i] = 1 when the i-th read in sorted order differs from the one before it
-__global__ __launch_bounds__(256) void k_prep_heads(const unsigned char* __restrict__ s,
+MUSC_KERNEL __launch_bounds__(256) void k_prep_heads(const unsigned char* __restrict__ s,
                                                     const uint64_t* __restrict__ off,
                                                     const uint32_t* __restrict__ perm, uint64_t n,
                                                     uint32_t* __restrict__ head) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_prep_heads(const unsigned char* __restr
 }
 
 // ustart[g] = position in sorted order where group g starts (gid = inclusive scan of head, minus 1)
-__global__ void k_prep_starts(const uint32_t* __restrict__ head, const uint32_t* __restrict__ incl, uint64_t n,
+MUSC_KERNEL void k_prep_starts(const uint32_t* __restrict__ head, const uint32_t* __restrict__ incl, uint64_t n,
                               uint32_t* __restrict__ ustart, uint32_t* __restrict__ uhead,
                               const uint32_t* __restrict__ perm) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -95,7 +95,7 @@ __global__ void k_prep_starts(const uint32_t* __restrict__ head, const uint32_t*
 
 // 2-bit records of the distinct reads: record g = input read uhead[g] (k_pack_reads with one
 // level of indirection)
-__global__ void k_prep_pack(const unsigned char* __restrict__ s, const uint64_t* __restrict__ off,
+MUSC_KERNEL void k_prep_pack(const unsigned char* __restrict__ s, const uint64_t* __restrict__ off,
                             const uint32_t* __restrict__ uhead, uint64_t nunique, int rw,
                             uint32_t* __restrict__ rd, uint32_t* __restrict__ rdm, uint32_t* __restrict__ has_x) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

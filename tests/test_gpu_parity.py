@@ -22,9 +22,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module", params=["auto", "quad", "classic"])
 def eng(request):
     """Every test of this module runs three times: on what the library picks by itself (context
-    buckets wherever the run fits them, with k_match_d -- dense comparison passes,
-    kernels_match_dense.hpp -- for up to two windows and k_match otherwise), with MUSC_MATCH=quad
-    (context buckets, always k_match) and with MUSC_INDEX=classic (64-byte buckets, k_screen ->
+    buckets wherever the run fits them, matched by k_match_t -- comparisons in the lane that owns the
+    read, kernels_match_lane.hpp), with MUSC_MATCH=quad (context buckets, k_match: the first fused
+    kernel, kept as a second implementation) and with MUSC_INDEX=classic (64-byte buckets, k_screen ->
     k_confirm)."""
     from muscato_amd import Engine
     old = {k: os.environ.get(k) for k in ("MUSC_INDEX", "MUSC_MATCH")}
@@ -504,6 +504,7 @@ def test_index_selection(monkeypatch):
     identical tuples either way."""
     from muscato_amd import Config, Engine, sorted_hits
     monkeypatch.delenv("MUSC_INDEX", raising=False)
+    monkeypatch.delenv("MUSC_MATCH", raising=False)
     rng = random.Random(2)
     targets = [rand_seq(rng, 400, b"ACGT") for _ in range(40)]
 
@@ -520,8 +521,8 @@ def test_index_selection(monkeypatch):
         ("one base too many", [0, 21], 100, b"ACGT", 0),
         ("four windows, 90 bp", [0, 10, 20, 30], 90, b"ACGT", 1),
         ("five windows", [0, 5, 10, 15, 20], 90, b"ACGT", 0),
-        ("reads with X, database without: k_match_d's RX form", [0, 20], 100, b"ACGTX", 1),
-        ("reads with X, three windows: k_match has no RX form", [0, 10, 20], 100, b"ACGTX", 0),
+        ("reads with X, database without: k_match_t lists a read's X in its xpos word", [0, 20], 100, b"ACGTX", 1),
+        ("reads with X, three windows", [0, 10, 20], 100, b"ACGTX", 1),
         ("long reads", [0, 20], 150, b"ACGT", 0),
     ]
     with Engine(0) as eng:
@@ -598,7 +599,7 @@ def test_graph_replay_of_the_sized_pass(monkeypatch):
 def test_batches_of_heavy_tiles_move_their_tuples_in_the_next_launch(monkeypatch):
     """Families of near-identical targets: a read has dozens of tuples, a wave-tile thousands (copy
     loops past the first 64, candidate lists spilling past LDS), in many small batches.  From the
-    second pass on k_match_d moves a batch's staged tuples from inside the next batch's launch
+    second pass on k_match_t moves a batch's staged tuples from inside the next batch's launch
     (last batch: k_compact_w; a last batch with a smaller grid: k_compact_w for the one before as
     well).  Every pass must return the single-batch list of the two-kernel path, in read-major
     order, with and without best + MMTol."""
@@ -656,9 +657,9 @@ def _x_in_reads_only(seed, n_targets, n_reads, xrate, heavy):
 @pytest.mark.parametrize("pmatch,ww,windows,fits", [(0.97, 15, (0, 20), True), (0.96, 12, (0, 20), True), (0.95, 15, (3, 20), False),
                                                     (0.97, 17, (0, 20), True)])
 def test_reads_with_x_against_an_x_free_database(eng, pmatch, ww, windows, fits):
-    """Reads with X (N in the FASTQ) against a database without any: on context buckets k_match_d
+    """Reads with X (N in the FASTQ) against a database without any: on context buckets k_match_t
     treats an X as a mismatch wherever the read lands and keeps windows that hold one from probing
-    (kernels_match_dense.hpp, RX).  A read with more X than its xpos word lists takes part only
+    (kernels_match_lane.hpp, rdx).  A read with more X than its xpos word lists takes part only
     if that many mismatches exceed its budget: 100 bp at PMatch 0.97 / 0.96 allows 3 / 4 < 5..9, at
     0.95 it allows 5 and the run takes the two-kernel path.  Tuples against the literal oracle."""
     from muscato_amd import sorted_hits
