@@ -238,6 +238,10 @@ int musc_gather(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hi
  * sit on distinct devices. */
 int musc_gather_rccl(musc_ctx* const* ctxs, int n, const uint64_t* read_base, musc_hit** hits,
                      uint64_t* nhits);
+/* Whether musc_gather_rccl can load librccl in this process: 0 = yes, 20 = no, with the reason
+ * copied into msg (at most cap bytes, NUL-terminated; msg may be NULL).  Needs no GPU.  The library
+ * is looked up once per process: MUSC_RCCL_LIB names it, else the ROCm tree's, else the loader's. */
+int musc_rccl_probe(char* msg, uint64_t cap);
 
 #ifdef __cplusplus
 }

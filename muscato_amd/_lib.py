@@ -58,7 +58,7 @@ SYMBOLS = [
     "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for",
     "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique",
     "musc_match_device", "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_free_hits",
-    "musc_get_stats", "musc_gather", "musc_gather_rccl", "musc_overflow_probes", "musc_free_u32",
+    "musc_get_stats", "musc_gather", "musc_gather_rccl", "musc_rccl_probe", "musc_overflow_probes", "musc_free_u32",
 ]
 
 _lib = None
@@ -108,10 +108,11 @@ def load() -> ctypes.CDLL:
     lib.musc_gather.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(u64),
                                 ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.musc_gather_rccl.argtypes = lib.musc_gather.argtypes
+    lib.musc_rccl_probe.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
     for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for", "musc_db_build_index_for",
                  "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique", "musc_match_device",
                  "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_get_stats",
-                 "musc_gather", "musc_gather_rccl"):
+                 "musc_gather", "musc_gather_rccl", "musc_rccl_probe"):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
     return lib

@@ -321,20 +321,23 @@ class Engine:
         return {k: getattr(s, k) for k, _ in s._fields_}
 
 
-def gather(engines: Sequence["Engine"], read_bases: Sequence[int], rccl: bool = True) -> np.ndarray:
+def gather(engines: Sequence["Engine"], read_bases: Sequence[int], rccl: bool = False) -> np.ndarray:
     """Concatenate the device-resident hits of several engines of ONE process in order, adding
-    read_bases[i] to the read_idx of engine i (musc_gather_rccl: over RCCL/xGMI to the first
-    engine's GPU and one copy to the host; musc_gather: every GPU copies its own).  uint32 [n, 4]."""
+    read_bases[i] to the read_idx of engine i (musc_gather: every GPU copies its own to the host;
+    rccl=True, opt-in: musc_gather_rccl, over RCCL/xGMI to the first engine's GPU and one copy to the
+    host -- any failure there falls back to musc_gather).  uint32 [n, 4]."""
     lib = engines[0]._lib
     n = len(engines)
     arr = (ctypes.c_void_p * n)(*[e._h for e in engines])
     bases = (ctypes.c_uint64 * n)(*[int(b) for b in read_bases])
     ph, cnt = ctypes.c_void_p(), ctypes.c_uint64()
-    fn = lib.musc_gather_rccl if rccl else lib.musc_gather
-    rc = fn(arr, n, bases, ctypes.byref(ph), ctypes.byref(cnt))
+    rc = lib.musc_gather_rccl(arr, n, bases, ctypes.byref(ph), ctypes.byref(cnt)) if rccl else 1
+    if rccl and rc == 2:  # a caller's mistake (contexts sharing a device, ...): not something to paper over
+        raise MuscatoError("musc_gather_rccl failed (%d): %s" % (rc, lib.musc_last_error(engines[0]._h).decode()))
     if rc != 0:
-        raise MuscatoError("%s failed (%d): %s" % ("musc_gather_rccl" if rccl else "musc_gather", rc,
-                                                   lib.musc_last_error(engines[0]._h).decode()))
+        rc = lib.musc_gather(arr, n, bases, ctypes.byref(ph), ctypes.byref(cnt))
+    if rc != 0:
+        raise MuscatoError("musc_gather failed (%d): %s" % (rc, lib.musc_last_error(engines[0]._h).decode()))
     out = np.zeros((cnt.value, 4), dtype=np.uint32)
     if cnt.value:
         ctypes.memmove(out.ctypes.data, ph, cnt.value * 16)

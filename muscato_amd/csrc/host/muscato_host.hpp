@@ -943,13 +943,16 @@ inline std::vector<musc_hit> run_hot_path(const Config& cfg, const std::vector<U
   if (err.empty()) {
     musc_hit* h = nullptr;
     uint64_t n = 0;
-    // the shards' tuples meet on the first GPU over RCCL/xGMI and leave it in one copy; without
-    // a usable librccl (return code 20) every GPU copies its own to the host instead
-    int grc = G > 1 ? musc_gather_rccl(ctxs.data(), G, base.data(), &h, &n) : musc_gather(ctxs.data(), G, base.data(), &h, &n);
-    if (grc == 20) {
-      log.printf("RCCL gather unavailable (%s): gathering through the host", musc_last_error(ctxs[0]));
+    // Every GPU copies its tuples to the host (musc_gather).  MUSC_GATHER=rccl (opt-in until it has run
+    // on a multi-GPU node) makes the shards' tuples meet on the first GPU over RCCL/xGMI and leave it
+    // in one copy; whatever goes wrong there, the host path takes over.
+    const char* genv = getenv("MUSC_GATHER");
+    const bool want_rccl = G > 1 && genv && !strcmp(genv, "rccl");
+    int grc = want_rccl ? musc_gather_rccl(ctxs.data(), G, base.data(), &h, &n) : musc_gather(ctxs.data(), G, base.data(), &h, &n);
+    if (want_rccl && grc != 0) {
+      log.printf("RCCL gather failed (%d: %s): gathering through the host", grc, musc_last_error(ctxs[0]));
       grc = musc_gather(ctxs.data(), G, base.data(), &h, &n);
-    } else if (G > 1 && grc == 0) {
+    } else if (want_rccl) {
       log.printf("tuples of %d GPUs gathered on GPU %d over RCCL", G, cfg.Device);
     }
     if (grc) err = musc_last_error(ctxs[0]);

@@ -24,6 +24,20 @@ DEV uint64_t mix64(uint64_t x) {
   return x;
 }
 
+// Hash of a (window, bucket) pair for the MaxMatches accounting (sketch cells and the exact block
+// table take its top bits): 32-bit multiply / xor-shift rounds -- full-rate instructions, where a
+// 64-bit mix costs a dozen quarter-rate multiplies per pair.  Every kernel that counts, and
+// k_hot_probes which names the suspects afterwards, must use the same function.
+DEV uint32_t block_hash32(uint32_t k, uint32_t b) {
+  uint32_t h = b ^ (k * 0x9E3779B9u + 0x7F4A7C15u);
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
 // 64 bits of a little-endian bit stream held in u32 words, starting at bit `bo`.
 DEV uint64_t ext64(const uint32_t* __restrict__ w, uint64_t bo) {
   const uint64_t i = bo >> 5;

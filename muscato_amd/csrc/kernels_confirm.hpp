@@ -273,9 +273,9 @@ __global__ __launch_bounds__(TILE, (RW <= 8 && !(RW == 8 && MASK)) ? 8 : 4) void
         const uint32_t cw = s_wcnt[t];
         if (!cw) continue;
         const uint32_t rl = t / pp.W, k = t % pp.W;
-        const uint64_t h = mix64(((uint64_t)k << 32) | wb[((uint64_t)tile * TILE + rl) * pp.W + k]);
-        if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - BLOCK_LDS_BITS)], cw);
-        else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
+        const uint32_t h = block_hash32((uint32_t)k, wb[((uint64_t)tile * TILE + rl) * pp.W + k]);
+        if (block_mode == 1) atomicAdd(&s_sketch[h >> (32 - BLOCK_LDS_BITS)], cw);
+        else atomicAdd(&block_table[h >> (32 - BLOCK_TABLE_BITS)], cw);
       }
     }
     lds_barrier();
@@ -376,8 +376,8 @@ __global__ __launch_bounds__(256) void k_hot_probes(const uint32_t* __restrict__
       if (len < q2) continue;
       if (pp.min_dinuc > 0 && rec_count_dinuc(rec, recm, has_m, q1, pp.ww) < pp.min_dinuc) continue;
       const uint32_t b = rec_bucket(rec, recm, has_m, q1, pp.ww, pp.bits, pp.direct);
-      const uint64_t h = mix64(((uint64_t)k << 32) | b);
-      if (block_table[h >> (64 - BLOCK_TABLE_BITS)] > max_matches) {
+      const uint32_t h = block_hash32((uint32_t)k, b);
+      if (block_table[h >> (32 - BLOCK_TABLE_BITS)] > max_matches) {
         const unsigned long long slot = atomicAdd(cursor, 1ull);
         if (slot < cap) out[slot] = make_uint2((uint32_t)i, (uint32_t)k);
       }

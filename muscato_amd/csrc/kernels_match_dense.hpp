@@ -501,9 +501,9 @@ __global__ __launch_bounds__(TILE, MATCHD_WAVES) void k_match_d(const uint32_t* 
           const uint32_t cw = wcnt_l[t];
           if (!cw) continue;
           const uint32_t kk = t >> 6;  // counters and buckets share the layout [window][read]
-          const uint64_t h = mix64(((uint64_t)kk << 32) | bb_l[t]);
-          if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - MATCH_SKETCH_BITS)], cw);
-          else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
+          const uint32_t h = block_hash32((uint32_t)kk, bb_l[t]);
+          if (block_mode == 1) atomicAdd(&s_sketch[h >> (32 - MATCH_SKETCH_BITS)], cw);
+          else atomicAdd(&block_table[h >> (32 - BLOCK_TABLE_BITS)], cw);
         }
       }
       wave_lds_sync();  // phases A..B of this tile are done with the per-tile LDS state

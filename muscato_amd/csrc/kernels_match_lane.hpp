@@ -1,7 +1,7 @@
 // k_match_t -- the fused screen + confirm + select kernel on context buckets with the comparisons done
-// IN THE LANE THAT OWNS THE READ (device code, included by muscato_hip.hip after kernels_match.hpp and
-// kernels_match_dense.hpp, whose bucket layout, parameter block, fit rules, cdiff and tuple staging
-// protocol it shares).
+// IN THE LANE THAT OWNS THE READ (device code; compiled in match_lane_rw*.hip, declared in
+// kernels_match_lane_inst.hpp; shares the bucket layout, parameter block, fit rules, cdiff and tuple
+// staging protocol of kernels_match.hpp / kernels_match_dense.hpp).
 //
 // k_match compares where a bucket line arrives (a quad of lanes per probe) and k_match_d moves the
 // entries that exist onto a stack in LDS and pops 64 of them per comparison pass.  Both spend most
@@ -15,8 +15,7 @@
 //   * the read's image for the window is built once per (read, window) from registers
 //     (read_image), not once per entry from LDS;
 //   * the three inline entries of the line are compared by three straight-line blocks with no
-//     memory access in them (the lane's registers hold count, target numbers, window positions and
-//     contexts): no stack, no entry copies, no per-entry meta / record / mask lookups;
+//     memory access in them: no stack, no entry copies, no per-entry meta / record / mask lookups;
 //   * best-per-read and the MaxMatches counters of (window, read) are registers of that lane.
 // 56 % of the slots of those blocks hold an entry (1.67 inline entries per probe on cfg3) -- less
 // than a dense pass, but a slot costs ~55 vector instructions and nothing else.
@@ -24,23 +23,61 @@
 // c ^ ((p >> 1) & 7) ^ (p & 1)), which makes both the quads' writes and the lanes' whole-line reads
 // bank-conflict free.
 //
-// Loads in flight: a ring of 4 x W register slots of 16 lines each -- one per (window, step) of a
-// wave-tile; the slot of step (k, rr) is refilled with the same step of the wave's NEXT wave-tile
-// the moment its lines have been written to LDS, so a wave has up to 64 x W lines in flight and
-// the buckets of a wave-tile are requested one whole wave-tile ahead (phase A of tile t + 1 runs at
-// the start of tile t, on records that were fetched during tile t - 1).
+// WHAT THE WAITS LOOK LIKE decides the schedule.  On gfx9 hipcc waits for a vector load with
+// s_waitcnt vmcnt(0) whenever a store may be pending or the loads after it sit under a branch (this
+// kernel: always) -- every wait drains everything the wave has in flight.  A ring of loads deeper
+// than "what the next wait needs" is therefore useless, and a wait right after an issue exposes a
+// whole memory latency.  So:
+//   * the ring is ONE window deep: after the 64 lines of window g have been written to LDS its four
+//     register slots are refilled with window g + 1 (the same wave-tile's next window, or the next
+//     wave-tile's first), which is what the next wait is for anyway;
+//   * nothing else is waited for fresh: the records of wave-tile t + 1 are fetched behind the last
+//     refill of tile t - 1 and used after the first wait of tile t; the entries beyond a bucket's
+//     third (CtxEntry in E, 10 % of the entries walked on cfg3) are loaded behind the last window's
+//     lines of tile t, a lane per entry, and compared after the first wait of tile t + 1; tile t's
+//     per-read selection (phase D) follows that pass, so records and candidate lists are
+//     double-buffered;
+//   * and no register spills: a scratch reload is a vector load whose wait drains the ring.
+// A wave thus alternates "64 lines in flight" with "compare a window": with two waves per SIMD one
+// computes while the other waits.
 //
-// The entries beyond a bucket's third (CtxEntry in E, 10 % of the entries walked on cfg3) take one
-// generic pass per wave-tile, a lane per entry, with the read's record from LDS (as k_match_d's
-// passes); their loads are issued before the last window's comparisons and consumed after them.
-//
-// LDS per workgroup of four waves: 4 x 14.2 KB + the MaxMatches sketch = 63 KB: two workgroups
-// per CU, two waves per SIMD -- what in-lane comparisons need is registers (ring 64, line 32,
-// records 24), not occupancy: their instruction stream has no LDS or memory latency to hide.
+// LDS per workgroup of four waves: 4 x 17.4 KB + the MaxMatches sketch = 78 KB: two workgroups per CU.
 #pragma once
 #include "kernels_match_lane_inst.hpp"
 
-template <int RW, int W>
+// single-instruction forms the compiler does not pick by itself (it re-associates the chains for
+// instruction-level parallelism the kernel has no use for: it is bound by the number of vector
+// instructions it issues)
+DEV uint32_t bcnt_add(uint32_t x, uint32_t acc) {  // popcount(x) + acc
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+DEV uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) {  // (a & b) | c
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+DEV uint32_t and_or_s(uint32_t a, uint32_t b, uint32_t c) {  // the same with b in a scalar register
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+// one bit per base at which two 2-bit streams differ (x = their XOR), under the mask m:
+// ((x | x >> 1) & m), the OR-AND as one v_bitop3
+DEV uint32_t base_diff(uint32_t x, uint32_t m) { return __builtin_amdgcn_bitop3_b32(x, x >> 1, m, 0xA8); }
+
+// utils/entropy.go:5-40 for a window of at most 16 bases without X: a dinucleotide is a 4-bit field
+// of the key; two instructions each (v_bfe_u32, v_lshl_or_b32)
+DEV int key_dinucs16(uint32_t key, int ww) {
+  uint32_t seen = 0;
+#pragma unroll
+  for (int i = 0; i < 15; i++)
+    if (i + 1 < ww) seen = (1u << __builtin_amdgcn_ubfe(key, 2 * i, 4)) | seen;
+  return __popc(seen);
+}
+
+template <int RW, int W, bool RX>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
@@ -57,32 +94,34 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
                                                                 const uint32_t* __restrict__ rdx) {
   static_assert(W >= 1 && W <= CTX_MAX_W, "context buckets serve at most CTX_MAX_W windows");
   constexpr int NWAVE = TILE / 64;
-  constexpr int RD = 4 * W;  // ring slots: one per (window, step of 16 probes)
-  constexpr int RPAD = 8;    // words in front of and behind a wave's records that a shifted window may touch
-  extern __shared__ uint32_t s_dyn[];  // block_mode != 0: NWAVE x W x 64 counters of the overflow pass, then (mode 1) the sketch
+  // block_mode != 0: 2 (tile parity) x NWAVE x W x 64 counters of the overflow passes, then (mode 1) the sketch
+  extern __shared__ uint32_t s_dyn[];
   __shared__ uint4 s_line[NWAVE][64 * 8];                 // the window's 64 bucket lines, swizzled
-  __shared__ __attribute__((aligned(16))) uint32_t s_rec[NWAVE][WT * RW + 2 * RPAD];  // the wave-tile's records (overflow pass)
-  __shared__ uint32_t s_meta[NWAVE][WT];                  // length | budget << 17 | valid windows << 24
-  __shared__ uint32_t s_bb[2][NWAVE][W * WT];             // bucket of (window, read), WB_NONE when the window takes no part; this tile's and the next one's
-  __shared__ uint32_t s_best[NWAVE][WT];                  // smallest mismatch count reported per read
-  __shared__ uint3 s_list[NWAVE][MATCH_WLIST];            // reported candidates: result word, gene, position
+  __shared__ __attribute__((aligned(16))) uint32_t s_rec[2][NWAVE][WT * RW];  // the records of this wave-tile and of the next
+  __shared__ uint32_t s_meta[2][NWAVE][WT];               // length | budget << 17 | valid windows << 24; this wave-tile's and the one before
+  __shared__ uint32_t s_xp[RX ? 2 : 1][RX ? NWAVE : 1][RX ? WT : 1];  // reads with X: their xpos words, likewise
+  __shared__ uint32_t s_best[2][NWAVE][WT];               // smallest mismatch count the overflow pass reported per read
+  __shared__ uint3 s_list[2][NWAVE][MATCHT_WLIST];        // reported candidates: result word, gene, position
   __shared__ uint32_t s_cb[NWAVE][2 * WT];                // phase D: cnt[64], base[64]
-  __shared__ uint32_t s_oix[NWAVE][WT];                   // overflow pass: item -> its entry in E
-  __shared__ uint8_t s_own[NWAVE][WT];                    //                item -> window * 64 + read slot
+  __shared__ uint32_t s_oix[NWAVE][WT];                   // overflow entries: item -> its entry in E
+  __shared__ uint8_t s_own[NWAVE][WT];                    //                   item -> window * 64 + read slot
   __shared__ uint16_t s_nm[CONF_NM];
-  __shared__ uint32_t s_xp[NWAVE][WT];                    // reads with X (rdx != nullptr): their xpos words (overflow pass)
 
-  const int ww = mp->ww, CL = mp->CL;
+  // the run's parameters: scalars for the whole kernel
+  const int ww = mp->ww, CL = mp->CL, min_dinuc = mp->min_dinuc, direct = mp->direct, bits = mp->bits;
   const uint32_t q1zero = mp->q1zero_mask;
-  const bool RX = rdx != nullptr;  // some read of the batch holds an X (wave-uniform)
-  uint32_t* const s_sketch = s_dyn + NWAVE * WT * W;
+  int win[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) win[k] = mp->win[k];
+  uint32_t* const s_sketch = s_dyn + 2 * NWAVE * WT * W;
   for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)mp->max_len ? nmiss_tab[t] : (uint16_t)0;
-  if (block_mode == 1)
-    for (uint32_t t = threadIdx.x; t < (1u << MATCH_SKETCH_BITS); t += TILE) s_sketch[t] = 0;
-  for (uint32_t t = threadIdx.x; t < NWAVE * 2 * RPAD; t += TILE) {  // the pads are read, never written again
-    const uint32_t wv = t / (2 * RPAD), o = t % (2 * RPAD);
-    s_rec[wv][o < RPAD ? o : WT * RW + o] = 0;
+  if (block_mode) {
+    for (uint32_t t = threadIdx.x; t < 2u * NWAVE * WT * W; t += TILE) s_dyn[t] = 0;
+    if (block_mode == 1)
+      for (uint32_t t = threadIdx.x; t < (1u << MATCH_SKETCH_BITS); t += TILE) s_sketch[t] = 0;
   }
+  s_best[0][threadIdx.x >> 6][threadIdx.x & 63] = 0xFFFFFFFFu;
+  s_best[1][threadIdx.x >> 6][threadIdx.x & 63] = 0xFFFFFFFFu;
   if (blockIdx.x == 0 && threadIdx.x == 0) tcount2[(n + WT - 1) / WT] = 0;
   __syncthreads();
 
@@ -96,78 +135,91 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   const uint32_t mmtol = (uint32_t)mp->mmtol;
   const bool apply = mp->apply_mmtol != 0;
 
-  auto fetch = [&](uint32_t wt, Rec<RW>& rec) {
+  auto fetch = [&](uint32_t wt, Rec<RW>& rec) __attribute__((always_inline)) {
     const uint32_t i = wt * WT + (opaque(threadIdx.x) & 63);
     rec.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);
   };
   // phase A of wave-tile wt, a lane per read: per window the length gate + CountDinuc >= MinDinuc
   // (cmd/muscato_window_reads/main.go:106-118 == cmd/muscato_screen/main.go:174-185) and the bucket
-  // of the window key -> s_bb[par].  Returns the windows that take part.
-  auto phase_a = [&](uint32_t wt, uint32_t par, const Rec<RW>& rec, uint32_t& xw) -> uint32_t {
-    const uint32_t tid = opaque(threadIdx.x);
-    const uint32_t lane = tid & 63, wid = tid >> 6;
-    uint32_t* const bb_l = s_bb[par][wid];
+  // of the window key -> bb[] (WB_NONE when the window takes no part).  Returns the windows that take part.
+  auto phase_a = [&](uint32_t wt, const Rec<RW>& rec, uint32_t& xw, uint32_t (&bb)[W]) __attribute__((always_inline)) -> uint32_t {
+    const uint32_t lane = opaque(threadIdx.x) & 63;
     const bool active = wt * WT + lane < n;
     const int len = (int)rec.len();
     uint32_t valid = 0;
-    // RX: windows that hold an X never probe; a read with more X than fit the word has no tuples
+    // reads with X: windows that hold one never probe; a read with more X than fit the word has no tuples
     xw = 0;
     uint32_t xwin = 0;  // windows barred by an X
-    if (RX) {
+    if constexpr (RX) {
       if (active && rec.has_x()) xw = rdx[r0 + wt * WT + lane];
       const uint32_t xc = XPOS_CNT(xw);
       if (xc > XPOS_MAX) xwin = 0xFFFFFFFFu;
 #pragma unroll
       for (int k = 0; k < W; k++) {
-        const uint32_t q1 = (uint32_t)mp->win[k];
+        const uint32_t q1 = (uint32_t)win[k];
 #pragma unroll
         for (int q = 0; q < XPOS_MAX; q++)
           if ((uint32_t)q < xc && XPOS_AT(xw, q) - q1 < (uint32_t)ww) xwin |= 1u << k;
       }
     }
-    if (ww <= 16 && mp->direct) {
+    if (ww <= 16 && direct) {
       // the usual case: the window key is one 32-bit word
       const uint32_t kmask = ww == 16 ? 0xFFFFFFFFu : ((1u << (2 * ww)) - 1u);
 #pragma unroll
       for (int k = 0; k < W; k++) {
-        const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
+        const uint32_t q1 = (uint32_t)win[k], q2 = q1 + (uint32_t)ww;
         const uint32_t key = (uint32_t)rec.ext(2 * q1) & kmask;
         bool pt = active && (uint32_t)len >= q2 && !((xwin >> k) & 1u);
-        if (mp->min_dinuc > 0) pt = pt && key_count_dinuc16(key, ww) >= mp->min_dinuc;
-        bb_l[k * WT + lane] = pt ? __brev(key) >> (32 - 2 * ww) : WB_NONE;
+#ifdef MUSC_LANE_DBG
+        if (min_dinuc > 0 && !(MUSC_LANE_DBG & 16)) pt = pt && key_dinucs16(key, ww) >= min_dinuc;
+#else
+        if (min_dinuc > 0) pt = pt && key_dinucs16(key, ww) >= min_dinuc;
+#endif
+        bb[k] = pt ? __brev(key) >> (32 - 2 * ww) : WB_NONE;
         valid |= pt ? 1u << k : 0u;
       }
     } else {
 #pragma unroll
       for (int k = 0; k < W; k++) {
         uint32_t b = WB_NONE;
-        const uint32_t q1 = (uint32_t)mp->win[k], q2 = q1 + (uint32_t)ww;
+        const uint32_t q1 = (uint32_t)win[k], q2 = q1 + (uint32_t)ww;
         if (active) {
           bool pt = (uint32_t)len >= q2 && !((xwin >> k) & 1u);
-          if (pt && mp->min_dinuc > 0)
-            pt = (ww <= 16 ? rec_count_dinuc16(rec, q1, ww) : rec_count_dinuc(rec, rec, false, q1, ww)) >= mp->min_dinuc;
+          if (pt && min_dinuc > 0)
+            pt = (ww <= 16 ? rec_count_dinuc16(rec, q1, ww) : rec_count_dinuc(rec, rec, false, q1, ww)) >= min_dinuc;
           if (pt) {
-            b = rec_bucket(rec, rec, false, q1, ww, mp->bits, mp->direct);
+            b = rec_bucket(rec, rec, false, q1, ww, bits, direct);
             valid |= 1u << k;
           }
         }
-        bb_l[k * WT + lane] = b;
+        bb[k] = b;
       }
     }
     nvalid += __popc(valid);
     return valid;
   };
-  // the bucket loads of one step (16 probes, a quad each: 32 bytes per lane)
-  auto issue = [&](uint32_t bpar, int k, int rr, uint4& a, uint4& b2) {
-    const uint32_t tid = opaque(threadIdx.x);
-    const uint32_t lane = tid & 63, wid = tid >> 6, part = lane & 3;
-    const uint32_t b = s_bb[bpar][wid][k * WT + rr * 16 + (lane >> 2)];
-    a.x = 0;  // a probe that takes no part reads as an empty bucket (count 0 in the quad's first lane)
-    if (b != WB_NONE) {
-      const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b) + 2 * part;
-      const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
-      a = make_uint4(x.x, x.y, x.z, x.w);
-      b2 = make_uint4(y.x, y.y, y.z, y.w);
+  // the bucket loads of one window: four steps of 16 probes, a quad of lanes per probe (32 bytes per
+  // lane).  bbk = this lane's read's bucket for that window; a quad gets its probe's bucket from the
+  // lane that owns the read (ds_bpermute: the LDS crossbar, no memory), all four steps before the
+  // first address is formed -- one round trip, not four.
+  auto issue_window = [&](uint32_t bbk, uint4 (&a)[4], uint4 (&b2)[4]) __attribute__((always_inline)) {
+    const uint32_t lane = opaque(threadIdx.x) & 63, part = lane & 3;
+    uint32_t b[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) b[rr] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rr * 16 + (lane >> 2)) * 4), (int)bbk);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      a[rr].x = 0;  // a probe that takes no part reads as an empty bucket (count 0 in the quad's first lane)
+#ifdef MUSC_LANE_DBG
+      if (b[rr] != WB_NONE && !(MUSC_LANE_DBG & 2)) {
+#else
+      if (b[rr] != WB_NONE) {
+#endif
+        const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b[rr]) + 2 * part;
+        const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
+        a[rr] = make_uint4(x.x, x.y, x.z, x.w);
+        b2[rr] = make_uint4(y.x, y.y, y.z, y.w);
+      }
     }
   };
 
@@ -183,7 +235,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     }
   }
   uint64_t pused = 0;  // tuples of the previous batch this wave has moved (its region is consumed in order)
-  auto pcopy_begin = [&](uint32_t wt, uint4& v, uint32_t& m, uint32_t& d) {
+  auto pcopy_begin = [&](uint32_t wt, uint4& v, uint32_t& m, uint32_t& d) __attribute__((always_inline)) {
     m = 0;
     d = 0;
     if (pcopy && wt < pnwt) {
@@ -194,7 +246,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       if (lane < m) v = pstage[region0 + pused + lane];
     }
   };
-  auto pcopy_end = [&](const uint4& v, uint32_t m, uint32_t d) {
+  auto pcopy_end = [&](const uint4& v, uint32_t m, uint32_t d) __attribute__((always_inline)) {
     if (!m) return;
     const uint32_t lane = opaque(threadIdx.x) & 63;
     uint4* __restrict__ dst = hits + pbase + d;
@@ -203,357 +255,409 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     pused += m;
   };
 
-  uint4 va[RD], vb[RD];
+  // What a comparison through window k reads of the host's tables (MatchParams), fetched in ONE batch
+  // of scalar loads per (wave-tile, window) -- a load inside the comparison would stall every entry:
+  //   lm    the length mask of a read of `len` bases placed through window k (one bit per base that
+  //         takes part in cdiff, in the coordinates of the context stream): a row of the host's table
+  //         when every read of the wave-tile has the same length ul, per-lane arithmetic otherwise
+  //   need  the windows whose exactness the comparison has to establish (first-window rule), and
+  //   wm    their masks
+  struct WinTab {
+    uint32_t lm[8];
+    uint32_t need;
+    uint32_t wm[W][8];
+  };
+  auto win_tab = [&](uint32_t ul, int k, uint32_t sh, uint32_t len, WinTab& tb) __attribute__((always_inline)) {
+    tb.need = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp->need[k]);
 #pragma unroll
-  for (int s = 0; s < RD; s++) va[s] = vb[s] = make_uint4(0, 0, 0, 0);
+    for (int kk = 0; kk < W; kk++) {
+      const uint32_t* __restrict__ row = mp->wm[k][kk];
+#pragma unroll
+      for (int j = 0; j < 8; j++) tb.wm[kk][j] = kk <= k ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row[j]) : 0u;  // (need[k] has no window beyond k)
+    }
+    if (ul != 0xFFFFFFFFu) {
+      const uint32_t* __restrict__ row = mp->lm[__builtin_amdgcn_readfirstlane((int)ul)][k];
+#pragma unroll
+      for (int j = 0; j < 8; j++) tb.lm[j] = row[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) tb.lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
+    }
+  };
+  // the X of a read in the image's coordinates
+  auto x_mask = [&](uint32_t xw, uint32_t sh, uint32_t (&xm)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) xm[j] = 0;
+    if constexpr (RX) {
+      if (__any(xw != 0)) {
+        const uint32_t xc = XPOS_CNT(xw);
+#pragma unroll
+        for (int q = 0; q < XPOS_MAX; q++) {
+          const uint32_t b = sh + 2u * XPOS_AT(xw, q);
+          const uint32_t bit = (uint32_t)q < xc ? 1u << (b & 31u) : 0u;
+#pragma unroll
+          for (int j = 0; j < 8; j++) xm[j] |= (b >> 5) == (uint32_t)j ? bit : 0u;
+        }
+      }
+    }
+  };
+  // one entry (context words c, c[7] still carrying the distance to the target end in its high half)
+  // against a read whose image for window k is img: the fit rules (ctx_fit), cdiff
+  // (cmd/muscato_confirm/main.go:151-159, 205-211: XOR, one bit per mismatching base, popcount) and,
+  // from the same mismatch mask, which windows of the read match the target exactly here (the pair is
+  // reported through the first of them only).  slot = the read's slot in its wave-tile.  Returns the
+  // pair's result word (NX_REJECT, or nmiss | NX_DUP | NX_ACC0 | window << 20 | slot << 24).
+  auto score = [&](bool live, int k, int q1, const uint32_t (&img)[8], const WinTab& tb, const uint32_t (&xm)[8], uint32_t jx,
+                   const uint32_t (&c)[8], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
+    // placements past the target's first bases (p = jx - q1 > 0) only have to end inside the target;
+    // the pos-0 rules are evaluated only when some lane of the wave is at p <= 0
+    uint32_t z = 0;
+    bool ok;
+    if (__any(live && jx <= (uint32_t)q1)) ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
+    else ok = live & (len - q1 <= (int)(c[7] >> 16));
+    ncmp += ok ? 1u : 0u;
+    uint32_t w = NX_REJECT;
+    if (ok) {
+      uint32_t d[8], nx = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        // (lm has no bit in the high half of word 7, where the context keeps the distance to the target end)
+        const uint32_t x = img[j] ^ c[j];
+        d[j] = RX ? ((x | (x >> 1)) | xm[j]) & tb.lm[j] : base_diff(x, tb.lm[j]);
+        nx = bcnt_add(d[j], nx);
+      }
+      uint32_t exact = valid & (z ? ~q1zero : 0xFFFFFFFFu);
+#pragma unroll
+      for (int kk = 0; kk < W; kk++) {
+        if (kk > k || !((tb.need >> kk) & 1u)) continue;  // wave-uniform
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc = and_or_s(d[j], tb.wm[kk][j], acc);
+        if (acc) exact &= ~(1u << kk);
+      }
+      // the reference's confirm for window k accepts the pair (it counts towards that window-key
+      // block's MaxMatches); the tuple is reported here only if k is the first window that accepts it
+      if (nx <= budget && ((exact >> k) & 1u)) {
+        const bool first = (uint32_t)(__ffs(exact) - 1) == (uint32_t)k;
+        w = (first ? nx : (nx | NX_DUP)) | NX_ACC0 | ((uint32_t)k << 20) | (slot << 24);
+      }
+    }
+    return w;
+  };
+
+  // ---- state of the wave-tile in hand ("cur": its records in s_rec[par], its meta / xpos words in
+  // s_meta[par] / s_xp[par], its candidates in s_list[par]), of the next one ("nx": records fetched
+  // into registers, then -- phase A -- into s_rec[par ^ 1]) and of the one before ("prev": its
+  // overflow entries ride in registers, a lane per entry with the read's record; their comparison
+  // pass and prev's phase D run inside cur's second window)
+  uint4 va[4], vb[4];  // the ring: the four steps of ONE window
+#pragma unroll
+  for (int s = 0; s < 4; s++) va[s] = vb[s] = make_uint4(0, 0, 0, 0);
   uint32_t par = 0;
-  Rec<RW> rec_cur, rec_nx;
-  rec_cur.zero();
+  Rec<RW> rec_nx;  // the records of the NEXT wave-tile, from their fetch to its phase A
   rec_nx.zero();
-  uint32_t valid_cur = 0, xw_cur = 0;
-  s_best[threadIdx.x >> 6][threadIdx.x & 63] = 0xFFFFFFFFu;
+  uint32_t meta_cur = 0, xw_cur = 0, bb_cur[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) bb_cur[k] = WB_NONE;
+  // prev
+  uint32_t wt_prev = 0, nlist_prev = 0, best_prev = 0xFFFFFFFFu, ulen_prev = 0xFFFFFFFFu, total_prev = 0;
+  uint32_t wc_prev[W], bb_prev[W], oc_prev[W], ovf_prev[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) wc_prev[k] = oc_prev[k] = ovf_prev[k] = 0, bb_prev[k] = WB_NONE;
+  // the first 64 overflow entries of prev, a lane per entry: which probe (window, read slot), the read's
+  // meta / xpos words and record (taken along when the entry was listed), and the entry itself as
+  // its three loads deliver it (gene, jx, ctx[0..1] | ctx[2..5] | ctx[6..7]): the loads' destination
+  // registers are carried to the pass as they are -- any re-packing would be a copy that waits for
+  // the data
+  uint32_t o_n = 0, o_k = 0, o_seg = 0, o_meta = 0, o_xw = 0;
+  Rec<RW> o_rec;
+  o_rec.zero();
+  u32x4_u o_a = {0, 0, 0, 0}, o_b = {0, 0, 0, 0};
+  uint2 o_d = make_uint2(0, 0);
+
+  // phase A of a wave-tile plus what its lanes keep of it: the meta word (length | budget << 17 | valid
+  // windows << 24); the record itself goes to s_rec[p]
+  auto phase_a_all = [&](uint32_t wt, uint32_t p, const Rec<RW>& rec, uint32_t& meta, uint32_t& xw, uint32_t (&bb)[W]) __attribute__((always_inline)) {
+    const uint32_t tid = opaque(threadIdx.x);
+    const uint32_t lane = tid & 63, wid = tid >> 6;
+    const uint32_t valid = phase_a(wt, rec, xw, bb);
+    const uint32_t len = rec.len();
+    const uint32_t budget0 = len < CONF_NM ? s_nm[len] : 0u;  // (reads on this path are at most 120 bases)
+    meta = len | ((budget0 > 127u ? 127u : budget0) << 17) | (valid << 24);
+    uint4* dst = reinterpret_cast<uint4*>(&s_rec[p][wid][lane * RW]);
+#pragma unroll
+    for (int q = 0; q < RW / 4; q++) dst[q] = make_uint4(rec.w[4 * q], rec.w[4 * q + 1], rec.w[4 * q + 2], rec.w[4 * q + 3]);
+  };
+  // the record of read slot `seg` of the wave-tile whose records are in s_rec[p]
+  auto rec_of = [&](uint32_t p, uint32_t seg, Rec<RW>& rec) __attribute__((always_inline)) {
+    const uint32_t wid = opaque(threadIdx.x) >> 6;
+    const uint4* src = reinterpret_cast<const uint4*>(&s_rec[p][wid][seg * RW]);
+#pragma unroll
+    for (int q = 0; q < RW / 4; q++) {
+      const uint4 v = src[q];
+      rec.w[4 * q] = v.x; rec.w[4 * q + 1] = v.y; rec.w[4 * q + 2] = v.z; rec.w[4 * q + 3] = v.w;
+    }
+  };
+
   if (gw < nwt) {
-    fetch(gw, rec_cur);
-    valid_cur = phase_a(gw, 0, rec_cur, xw_cur);
+    Rec<RW> rec0;
+    fetch(gw, rec0);
+    phase_a_all(gw, 0, rec0, meta_cur, xw_cur, bb_cur);
     if (gw + nw < nwt) fetch(gw + nw, rec_nx);
     wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < W; k++)
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) issue(0, k, rr, va[k * 4 + rr], vb[k * 4 + rr]);
+    issue_window(bb_cur[0], va, vb);
   }
   uint32_t wt = gw;
-  for (; wt < nwt; wt += nw) {
-    uint4 cpv = make_uint4(0, 0, 0, 0);
-    uint32_t cpm, cpd;
-    pcopy_begin(wt, cpv, cpm, cpd);
+  bool have_prev = false;
+#ifdef MUSC_LANE_PROF
+  unsigned long long pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime(), pstart = pt0;
+  uint32_t pf_tiles = 0;
+#define PF(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf[i] += t_ - pt0; pt0 = t_; }
+#elif defined(MUSC_LANE_MARK)
+#define PF(i) asm volatile("; MARK " #i);
+#else
+#define PF(i)
+#endif
+  while (wt < nwt || have_prev) {
+    const bool have_cur = wt < nwt;
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6, part = lane & 3;
-    uint32_t* const wcnt_l = s_dyn + wid * WT * W;
-    uint32_t* const best_l = s_best[wid];
     uint32_t* const cnt_l = s_cb[wid];
     uint32_t* const base_l = s_cb[wid] + WT;
-    const uint32_t* const rec_l = s_rec[wid] + RPAD;
     uint4* const line_l = s_line[wid];
     const bool have_next = wt + nw < nwt;
-    const bool active = wt * WT + lane < n;
 
-    // ---- the next wave-tile's buckets (its records were fetched during the previous wave-tile), then
-    // the fetch of the records after those
-    uint32_t valid_nx = 0, xw_nx = 0;
-    Rec<RW> rec_pre;
-    rec_pre.zero();
-    if (have_next) {
-      valid_nx = phase_a(wt + nw, par ^ 1u, rec_nx, xw_nx);
-      if (wt + 2 * nw < nwt) fetch(wt + 2 * nw, rec_pre);
-    }
-    // this wave-tile's per-read state: registers of the read's lane; the record and the meta word
-    // also go to LDS for the overflow pass
-    const int rlen = (int)rec_cur.len();
-    const uint32_t budget = rlen < CONF_NM ? s_nm[rlen] : 0u;  // (reads on this path are at most 120 bases)
-    {
-      uint4* dst = reinterpret_cast<uint4*>(&s_rec[wid][RPAD + lane * RW]);
-#pragma unroll
-      for (int q = 0; q < RW / 4; q++)
-        dst[q] = make_uint4(rec_cur.w[4 * q], rec_cur.w[4 * q + 1], rec_cur.w[4 * q + 2], rec_cur.w[4 * q + 3]);
-      s_meta[wid][lane] = (uint32_t)rlen | ((budget > 127u ? 127u : budget) << 17) | (valid_cur << 24);
-      if (RX) s_xp[wid][lane] = xw_cur;
-      if (block_mode)
-        for (uint32_t t = lane; t < WT * (uint32_t)W; t += 64) wcnt_l[t] = 0;
-    }
-    // every read of the wave-tile of one length: the comparisons use scalar length masks
-    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(rlen);
-    const uint32_t ulen = __ballot(active && (uint32_t)rlen != len0) == 0 ? len0 : 0xFFFFFFFFu;
-    wave_lds_sync();
-
-    uint32_t nlist = 0;          // reported candidates of this wave-tile so far (wave-uniform)
-    uint32_t best = 0xFFFFFFFFu; // smallest mismatch count reported for this lane's read by the in-lane comparisons
-    uint32_t wc[W];              // accepted pairs of (window, this lane's read): MaxMatches accounting
-    uint32_t oc[W], ovf[W];      // entries beyond the third of this lane's probe of window k, and where in E
-#pragma unroll
-    for (int k = 0; k < W; k++) wc[k] = oc[k] = ovf[k] = 0;
-
-    // a reported candidate of the lane's own read (in-lane comparisons): appended in lane order
-    auto report_own = [&](uint32_t w, uint32_t gene, uint32_t pos, uint32_t& wck) {
+    // a reported candidate of any read of a wave-tile (overflow entries): list / counters of parity p
+    auto report_any = [&](uint32_t p, uint32_t& nl, uint32_t w, uint32_t gene, uint32_t pos) __attribute__((always_inline)) {
       const bool acc = w != NX_REJECT;
-      wck += acc ? 1u : 0u;
+      if (acc && block_mode) atomicAdd(&s_dyn[(p * NWAVE + wid) * WT * W + ((w >> 20) & 15u) * WT + (w >> 24)], 1u);
       const bool rep = acc && !(w & NX_DUP);
       const unsigned long long vote = __ballot(rep);
       if (vote == 0) return;
       const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
-      const uint32_t slot = nlist + below;
-      nlist += (uint32_t)__popcll(vote);
+      const uint32_t slot = nl + below;
+      nl += (uint32_t)__popcll(vote);
       if (!rep) return;
-      const uint32_t v = w & 0xFFFFu;
-      best = v < best ? v : best;
-      if (slot < MATCH_WLIST) {
-        s_list[wid][slot] = make_uint3(w, gene, pos);
-      } else if (slot - MATCH_WLIST < sregion) {
-        spill[sregion0 + (slot - MATCH_WLIST)] = make_uint4(w, gene, pos, 0u);
+      atomicMin(&s_best[p][wid][w >> 24], w & 0xFFFFu);
+      if (slot < MATCHT_WLIST) {
+        s_list[p][wid][slot] = make_uint3(w, gene, pos);
+      } else if (slot - MATCHT_WLIST < sregion) {
+        spill[sregion0 + (slot - MATCHT_WLIST)] = make_uint4(w, gene, pos, 0u);
       }
     };
-    // a reported candidate of any read of the wave-tile (overflow pass)
-    auto report_any = [&](uint32_t w, uint32_t gene, uint32_t pos) {
-      const bool acc = w != NX_REJECT;
-      if (acc && block_mode) atomicAdd(&wcnt_l[((w >> 20) & 15u) * WT + (w >> 24)], 1u);
-      const bool rep = acc && !(w & NX_DUP);
-      const unsigned long long vote = __ballot(rep);
-      if (vote == 0) return;
-      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
-      const uint32_t slot = nlist + below;
-      nlist += (uint32_t)__popcll(vote);
-      if (!rep) return;
-      atomicMin(&best_l[w >> 24], w & 0xFFFFu);
-      if (slot < MATCH_WLIST) {
-        s_list[wid][slot] = make_uint3(w, gene, pos);
-      } else if (slot - MATCH_WLIST < sregion) {
-        spill[sregion0 + (slot - MATCH_WLIST)] = make_uint4(w, gene, pos, 0u);
-      }
-    };
-
-    // what the overflow pass keeps between the issue of its loads and their use
-    uint32_t o_total = 0, o_k = 0, o_seg = 0, o_gene = 0, o_jx = 0;
-    uint32_t o_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t o_pre[W];
+    // The comparison pass over overflow entries, a lane per entry: entry (ea | eb | ed), the probe it
+    // belongs to (window ek, read slot seg) and that read's meta / xpos words and record; the first
+    // n_items lanes hold one.  Candidates go to the lists of parity p.
+    auto entry_compare = [&](uint32_t p, uint32_t& nl, uint32_t ul, uint32_t n_items, uint32_t ek, uint32_t seg, uint32_t meta,
+                             uint32_t xw, const Rec<RW>& rec, const u32x4_u& ea, const u32x4_u& eb, const uint2& ed) __attribute__((always_inline)) {
+#ifdef MUSC_LANE_DBG
+      if (MUSC_LANE_DBG & 32) return;
+#endif
+      const bool have = lane < n_items;
+      if (!__any(have)) return;
+      const int len = (int)REC_LEN(meta);
+      const uint32_t gene = ea.x, jx = ea.y;
+      const uint32_t c[8] = {ea.z, ea.w, eb.x, eb.y, eb.z, eb.w, ed.x, ed.y};
+      if (W == 2 && direct) {
+        // Two windows, a table whose bucket is the key (the usual case): ONE pass with the window per
+        // lane -- the read's image for either window, the lane's window's length mask, and the only
+        // exactness to establish is window 0's for the entries that came through window 1.
+        const bool k1 = have && ek != 0;
+        const int q1a = win[0], q1b = win[W - 1];
+        const uint32_t sha = 2u * (uint32_t)(CL - q1a), shb = 2u * (uint32_t)(CL - q1b);
+        const uint32_t sh = k1 ? shb : sha;
+        const int q1 = k1 ? q1b : q1a;
+        uint32_t lm[8];
+        if (ul != 0xFFFFFFFFu) {
+          const uint32_t (*rows)[8] = mp->lm[__builtin_amdgcn_readfirstlane((int)ul)];
 #pragma unroll
-    for (int k = 0; k < W; k++) o_pre[k] = 0;
-    // chunk c0 of the overflow items: owner tables, then a lane per item loads its entry
-    auto overflow_issue = [&](uint32_t c0) {
+          for (int j = 0; j < 8; j++) lm[j] = k1 ? rows[W - 1][j] : rows[0][j];
+        } else {
 #pragma unroll
-      for (int k = 0; k < W; k++) {
-        // this lane's items of window k that fall into [c0, c0 + 64)
-        const uint32_t e_lo = c0 > o_pre[k] ? c0 - o_pre[k] : 0u;
-        const uint32_t e_hi = o_pre[k] + oc[k] > c0 + WT ? (c0 + WT > o_pre[k] ? c0 + WT - o_pre[k] : 0u) : oc[k];
-        for (uint32_t e = e_lo; e < e_hi; e++) {
-          s_own[wid][o_pre[k] + e - c0] = (uint8_t)(k * WT + lane);
-          s_oix[wid][o_pre[k] + e - c0] = ovf[k] + e;
+          for (int j = 0; j < 8; j++) lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * len - 32 * j);
         }
-      }
-      wave_lds_sync();
-      if (c0 + lane < o_total) {
-        const uint32_t probe = s_own[wid][lane];
-        o_k = probe >> 6;
-        o_seg = probe & 63u;
-        const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E + (uint64_t)s_oix[wid][lane]);
-        const uint2 hd = *reinterpret_cast<const uint2*>(pe);
-        const u32x4_u x = *reinterpret_cast<const u32x4_u*>(pe + 2);
-        const u32x4_u y = *reinterpret_cast<const u32x4_u*>(pe + 6);
-        o_gene = hd.x;
-        o_jx = hd.y;
-        o_c[0] = x.x; o_c[1] = x.y; o_c[2] = x.z; o_c[3] = x.w; o_c[4] = y.x; o_c[5] = y.y; o_c[6] = y.z; o_c[7] = y.w;
-      }
-      wave_lds_sync();  // the owner tables may be rewritten
-    };
-
-    // the length mask of a read of `len` bases placed through window k (one bit per base that takes part
-    // in cdiff, in the coordinates of the context stream): a row of the host's table when every read
-    // of the wave-tile has the same length (scalar loads), per-lane arithmetic otherwise
-    auto length_mask = [&](int k, uint32_t sh, uint32_t len, uint32_t (&lm)[8]) {
-      if (ulen != 0xFFFFFFFFu) {
-        const uint32_t* __restrict__ row = mp->lm[__builtin_amdgcn_readfirstlane((int)ulen)][k];
+        uint32_t wm0[8];  // window 0 of the read, in the coordinates of a comparison through window 1
+        {
+          const uint32_t* __restrict__ row = mp->wm[W - 1][0];
 #pragma unroll
-        for (int j = 0; j < 8; j++) lm[j] = row[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
-      }
-    };
-    // the X of a read in the image's coordinates (RX)
-    auto x_mask = [&](uint32_t xw, uint32_t sh, uint32_t (&xm)[8]) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) xm[j] = 0;
-      if (RX) {
-        if (__any(xw != 0)) {
-          const uint32_t xc = XPOS_CNT(xw);
-#pragma unroll
-          for (int q = 0; q < XPOS_MAX; q++) {
-            const uint32_t b = sh + 2u * XPOS_AT(xw, q);
-            const uint32_t bit = (uint32_t)q < xc ? 1u << (b & 31u) : 0u;
-#pragma unroll
-            for (int j = 0; j < 8; j++) xm[j] |= (b >> 5) == (uint32_t)j ? bit : 0u;
-          }
+          for (int j = 0; j < 8; j++) wm0[j] = row[j];
         }
-      }
-    };
-    // a generic comparison of the overflow pass: the entry is in this lane, the read (slot seg) in LDS
-    auto compare_any = [&](uint32_t k, int q1, uint32_t sh, uint32_t seg, uint32_t jx, bool live, const uint32_t (&c)[8]) -> uint32_t {
-      const uint32_t meta = s_meta[wid][seg];
-      const int len_s = (int)REC_LEN(meta);
-      uint32_t z = 0;
-      bool ok;
-      if (__any(live && jx <= (uint32_t)q1)) ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, len_s, &z);
-      else ok = live & (len_s - q1 <= (int)(c[7] >> 16));
-      {
-        const unsigned long long okv = __ballot(ok);
-        ncmp += lane == 0 ? (uint32_t)__popcll(okv) : 0u;
-      }
-      uint32_t w = NX_REJECT;
-      if (ok) {
-        const uint32_t wo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sh >> 5)), bs = sh & 31u;
-        const uint32_t* rp = rec_l + seg * RW - wo;
-        uint32_t x[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) x[j] = rp[j - 1];
-        uint32_t img[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) img[j] = bs ? __builtin_amdgcn_alignbit(x[j + 1], x[j], 32u - bs) : x[j + 1];
-        uint32_t cc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) cc[j] = c[j];
-        cc[7] &= 0xFFFFu;
-        const uint32_t exact0 = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
-        uint32_t lm[8], xm[8];
-        length_mask((int)k, sh, (uint32_t)len_s, lm);
-        uint32_t xw = 0;
-        if (RX) xw = s_xp[wid][seg];
-        x_mask(xw, sh, xm);
-        w = ctx_score<true, true>(img, cc, sh, k, mp, W, exact0, REC_BUDGET(meta), seg, (uint32_t)len_s, lm, xm);
-      }
-      return w;
-    };
-
-#pragma unroll
-    for (int k = 0; k < W; k++) {
-      const int q1 = mp->win[k];
-      const uint32_t sh = opaque_s(2u * (uint32_t)(CL - q1));
-      // ---- arrival: the quads write the lines they fetched into the line buffer (swizzled), and
-      // each ring slot is refilled with the same step of the next wave-tile
-      {
-        const uint32_t q = lane >> 2;
-        const uint32_t sw = ((q >> 1) & 7u) ^ (q & 1u);
-        const uint32_t wb0 = q * 8u + ((2u * part) ^ sw);  // in units of 16 bytes; the line's second half: ^ 1
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          line_l[rr * 128 + wb0] = va[k * 4 + rr];
-          line_l[rr * 128 + (wb0 ^ 1u)] = vb[k * 4 + rr];
-          if (have_next) issue(par ^ 1u, k, rr, va[k * 4 + rr], vb[k * 4 + rr]);
-        }
-      }
-      wave_lds_sync();
-      // ---- transpose: lane p takes line p -- its header now, an entry's context when its turn comes
-      const uint32_t rb = lane * 8u + (((lane >> 1) & 7u) ^ (lane & 1u));
-      const uint4 h0 = line_l[rb], h1 = line_l[rb ^ 1u];
-      uint4 ca = line_l[rb ^ 2u], cb = line_l[rb ^ 3u];
-      const uint32_t cnt = h0.x;
-      ncand += cnt;
-      oc[k] = cnt > CTX_INLINE ? cnt - CTX_INLINE : 0u;
-      ovf[k] = h0.y;
-      novf += oc[k];
-      // the entries beyond the third: their loads go out before the last window's comparisons
-      if (k + 1 == W) {
-        uint32_t total = 0;
-#pragma unroll
-        for (int kk = 0; kk < W; kk++) {
-          const uint32_t inc = wave_scan_incl(oc[kk]);
-          o_pre[kk] = total + inc - oc[kk];
-          total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        }
-        o_total = total;
-        if (total) overflow_issue(0);
-      }
-      // ---- the read's image for this window, then the line's three entries, in this lane
-      uint32_t img[8], lm[8], xm[8];
-      read_image<RW>(rec_cur, sh, img);
-      length_mask(k, sh, (uint32_t)rlen, lm);
-      x_mask(xw_cur, sh, xm);
-#pragma unroll
-      for (int s = 0; s < CTX_INLINE; s++) {
-        const bool live = (uint32_t)s < cnt;
-        if (!__any(live)) break;
-        uint4 na = ca, nb = cb;
-        if (s + 1 < CTX_INLINE) {  // the next entry's context is on its way while this one is compared
-          na = line_l[rb ^ (uint32_t)(2 * s + 4)];
-          nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
-        }
-        const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
-        const uint32_t jx = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
-        uint32_t c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-        // placements past the target's first bases (p = jx - q1 > 0) only have to end inside the
-        // target; the pos-0 rules are evaluated only when some lane of the wave is at p <= 0
         uint32_t z = 0;
         bool ok;
-        if (__any(live && jx <= (uint32_t)q1)) ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, rlen, &z);
-        else ok = live & (rlen - q1 <= (int)(c[7] >> 16));
-        {
-          const unsigned long long okv = __ballot(ok);
-          ncmp += lane == 0 ? (uint32_t)__popcll(okv) : 0u;
-        }
+        if (__any(have && jx <= (uint32_t)q1)) ok = have & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
+        else ok = have & (len - q1 <= (int)(c[7] >> 16));
+        ncmp += ok ? 1u : 0u;
         uint32_t w = NX_REJECT;
         if (ok) {
-          c[7] &= 0xFFFFu;
-          const uint32_t exact0 = valid_cur & (z ? ~q1zero : 0xFFFFFFFFu);
-          w = ctx_score<true, true>(img, c, sh, (uint32_t)k, mp, W, exact0, budget > 127u ? 127u : budget, lane, (uint32_t)rlen, lm, xm);
+          uint32_t ia[8], ib[8], xm[8];
+          read_image<RW>(rec, sha, ia);
+          read_image<RW>(rec, shb, ib);
+          x_mask(xw, sh, xm);
+          uint32_t d[8], nx = 0, acc0 = 0;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t df = (k1 ? ib[j] : ia[j]) ^ c[j];
+            d[j] = RX ? ((df | (df >> 1)) | xm[j]) & lm[j] : base_diff(df, lm[j]);
+            nx = bcnt_add(d[j], nx);
+            acc0 = and_or_s(d[j], wm0[j], acc0);
+          }
+          uint32_t exact = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
+          if (k1 && acc0) exact &= ~1u;
+          const uint32_t kbit = k1 ? 2u : 1u;
+          if (nx <= REC_BUDGET(meta) && (exact & kbit)) {
+            const bool first = (exact & (kbit - 1u)) == 0;
+            w = (first ? nx : (nx | NX_DUP)) | NX_ACC0 | (k1 ? 1u << 20 : 0u) | (seg << 24);
+          }
         }
-        report_own(w, gene, jx - (uint32_t)q1, wc[k]);
-        ca = na;
-        cb = nb;
+        report_any(p, nl, w, gene, jx - (uint32_t)q1);
+        return;
       }
-      wave_lds_sync();  // (the next window's arrival writes come after this window's reads)
-    }
-
-    // ---- the overflow pass: a lane per entry beyond a bucket's third, all windows of the wave-tile
-    for (uint32_t c0 = 0; c0 < o_total; c0 += WT) {
-      if (c0) overflow_issue(c0);
-      const bool have = c0 + lane < o_total;
       uint32_t w = NX_REJECT;
       int q1 = 0;
 #pragma unroll
       for (int kk = 0; kk < W; kk++) {
-        const bool mine = have && o_k == (uint32_t)kk;
+        const bool mine = have && ek == (uint32_t)kk;
         if (!__any(mine)) continue;
-        const int q1k = mp->win[kk];
-        const uint32_t shk = opaque_s(2u * (uint32_t)(CL - q1k));
-        const uint32_t w2 = compare_any((uint32_t)kk, q1k, shk, o_seg, o_jx, mine, o_c);
+        const int q1k = win[kk];
+        const uint32_t shk = 2u * (uint32_t)(CL - q1k);
+        WinTab tb;
+        win_tab(ul, kk, shk, (uint32_t)len, tb);
+        uint32_t img[8], xm[8];
+        read_image<RW>(rec, shk, img);
+        x_mask(xw, shk, xm);
+        const uint32_t w2 = score(mine, kk, q1k, img, tb, xm, jx, c, len, REC_BUDGET(meta), REC_VALID(meta), seg);
         if (mine) {
           w = w2;
           q1 = q1k;
         }
       }
-      report_any(w, o_gene, o_jx - (uint32_t)q1);
-    }
-    wave_lds_sync();
-
-    // ---- phase D: per-read selection and the tuples (as in k_match_d)
-    {
-      const uint32_t nl = nlist;
-      const uint32_t nspill = nl > MATCH_WLIST ? nl - MATCH_WLIST : 0u;
+      report_any(p, nl, w, gene, jx - (uint32_t)q1);
+    };
+    // The loads of prev's first 64 overflow entries (their places in E were listed, s_oix, when prev's
+    // last window arrived).  Issued right after a wait that left nothing in flight and straight into
+    // the registers the pass reads after the NEXT wait: no copy, no wait of their own.  Every lane
+    // loads -- the ones past the last item entry 0 of E, which always exists.
+    auto entry_fetch = [&]() __attribute__((always_inline)) {
+      const uint32_t eix = lane < o_n ? s_oix[wid][lane] : 0u;
+      const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E + (uint64_t)eix);
+      o_a = *reinterpret_cast<const u32x4_u*>(pe);
+      o_b = *reinterpret_cast<const u32x4_u*>(pe + 4);
+      o_d = *reinterpret_cast<const uint2*>(pe + 8);
+    };
+    // owner tables of the overflow items [c0, c0 + 64) of a wave-tile: item -> (window, read slot) and its
+    // place in E; oc / ovf / pre: per lane (= probe) the number of entries beyond the third, where
+    // they start in E, and the items before them
+    auto owner_tables = [&](uint32_t c0, const uint32_t (&oc)[W], const uint32_t (&ovf)[W], const uint32_t (&pre)[W]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kk = 0; kk < W; kk++) {
+        const uint32_t e_lo = c0 > pre[kk] ? c0 - pre[kk] : 0u;
+        const uint32_t e_hi = pre[kk] + oc[kk] > c0 + WT ? (c0 + WT > pre[kk] ? c0 + WT - pre[kk] : 0u) : oc[kk];
+#pragma unroll 1
+        for (uint32_t e = e_lo; e < e_hi; e++) {
+          s_own[wid][pre[kk] + e - c0] = (uint8_t)(kk * WT + lane);
+          s_oix[wid][pre[kk] + e - c0] = ovf[kk] + e;
+        }
+      }
+      wave_lds_sync();
+    };
+    // prev's overflow entries beyond the first 64 (families of near-identical targets, low-complexity
+    // keys): listed, loaded and compared on the spot, 64 at a time; their reads' records come from
+    // global memory (prev's place in LDS belongs to the next wave-tile by now)
+    auto overflow_rest_prev = [&]() __attribute__((always_inline)) {
+      if (total_prev <= (uint32_t)WT) return;
+      const uint32_t pp = par ^ 1u;
+      uint32_t pre[W], total = 0;
+#pragma unroll
+      for (int kk = 0; kk < W; kk++) {
+        const uint32_t inc = wave_scan_incl(oc_prev[kk]);
+        pre[kk] = total + inc - oc_prev[kk];
+        total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      }
+      for (uint32_t c0 = WT; c0 < total; c0 += WT) {
+        owner_tables(c0, oc_prev, ovf_prev, pre);
+        const uint32_t cnt = total - c0 < (uint32_t)WT ? total - c0 : (uint32_t)WT;
+        const bool mine = lane < cnt;
+        const uint32_t probe = mine ? (uint32_t)s_own[wid][lane] : 0u;
+        const uint32_t eix = mine ? s_oix[wid][lane] : 0u;
+        const uint32_t ek = probe >> 6, seg = probe & 63u;
+        const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E + (uint64_t)eix);
+        const u32x4_u ta = *reinterpret_cast<const u32x4_u*>(pe);
+        const u32x4_u tb2 = *reinterpret_cast<const u32x4_u*>(pe + 4);
+        const uint2 td = *reinterpret_cast<const uint2*>(pe + 8);
+        Rec<RW> trec;
+        trec.load(rd + (r0 + (uint64_t)wt_prev * WT + seg) * (uint64_t)RW, RW);
+        const uint32_t tmeta = s_meta[pp][wid][seg];
+        uint32_t txw = 0;
+        if constexpr (RX) txw = s_xp[pp][wid][seg];
+        wave_lds_sync();  // (the owner tables are rewritten by the next chunk)
+        entry_compare(pp, nlist_prev, ulen_prev, cnt, ek, seg, tmeta, txw, trec, ta, tb2, td);
+      }
+    };
+    // phase D for prev: per-read selection and the tuples (as in k_match_d)
+    auto phase_d_prev = [&]() __attribute__((always_inline)) {
+#ifdef MUSC_LANE_DBG
+      if (MUSC_LANE_DBG & 8) return;
+#endif
+      const uint32_t pp = par ^ 1u;
+      uint32_t* const best_l = s_best[pp][wid];
+      uint32_t* const wcnt_l = s_dyn + (pp * NWAVE + wid) * WT * W;
+      const uint32_t nl = nlist_prev;
+      const uint32_t nspill = nl > MATCHT_WLIST ? nl - MATCHT_WLIST : 0u;
       const bool spill_ok = nspill <= sregion;
       if (nspill > maxspill) maxspill = nspill;
       if (nspill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's spilled candidates have landed
       if (block_mode) {
-        const uint32_t* const bb_l = s_bb[par][wid];
 #pragma unroll
         for (int k = 0; k < W; k++) {
-          const uint32_t cw = wc[k] + wcnt_l[k * WT + lane];
+          const uint32_t cw = wc_prev[k] + wcnt_l[k * WT + lane];
+          wcnt_l[k * WT + lane] = 0;
           if (!cw) continue;
-          const uint64_t h = mix64(((uint64_t)k << 32) | bb_l[k * WT + lane]);
-          if (block_mode == 1) atomicAdd(&s_sketch[h >> (64 - MATCH_SKETCH_BITS)], cw);
-          else atomicAdd(&block_table[h >> (64 - BLOCK_TABLE_BITS)], cw);
+          const uint32_t h = block_hash32((uint32_t)k, bb_prev[k]);
+          if (block_mode == 1) atomicAdd(&s_sketch[h >> (32 - MATCH_SKETCH_BITS)], cw);
+          else atomicAdd(&block_table[h >> (32 - BLOCK_TABLE_BITS)], cw);
         }
       }
-      pcopy_end(cpv, cpm, cpd);
       // the lane's own best joins what the overflow pass found for its read
       {
         const uint32_t b0 = best_l[lane];
-        best_l[lane] = best < b0 ? best : b0;
+        best_l[lane] = best_prev < b0 ? best_prev : b0;
       }
       cnt_l[lane] = 0;
       wave_lds_sync();
-      auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) -> uint32_t {
-        if (j < MATCH_WLIST) {
-          const uint3 it = s_list[wid][j];
+      auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) __attribute__((always_inline)) -> uint32_t {
+        if (j < MATCHT_WLIST) {
+          const uint3 it = s_list[pp][wid][j];
           *gene = it.y;
           *pos = it.z;
           return it.x;
         }
         // written by other lanes of this wave a moment ago: read past the L1
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(spill + sregion0 + (j - MATCH_WLIST));
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(spill + sregion0 + (j - MATCHT_WLIST));
         *gene = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *pos = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
-      const uint32_t nuse = spill_ok ? nl : (nl < MATCH_WLIST ? nl : MATCH_WLIST);
-      for (uint32_t j = lane; j < nuse; j += 64) {
+      const uint32_t nuse = spill_ok ? nl : (nl < MATCHT_WLIST ? nl : MATCHT_WLIST);
+      // The first two rounds of candidates (a lane each: 128 of them, cfg3 has ~53 per wave-tile) stay
+      // in registers from the count to the store: the counting atomic also hands out the tuple's
+      // place among its read's; further rounds (spilled lists) are walked twice.
+      uint32_t kw[2], kg[2], kp[2], ko[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        kw[q] = NX_REJECT;
+        kg[q] = kp[q] = ko[q] = 0;
+        const uint32_t j = (uint32_t)q * 64 + lane;
+        if (j < nuse) {
+          const uint32_t w = item(j, &kg[q], &kp[q]);
+          const uint32_t rl = w >> 24;
+          const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
+          if ((w & 0xFFFFu) <= thr) {
+            kw[q] = w;
+            ko[q] = atomicAdd(&cnt_l[rl], 1u);
+          }
+        }
+      }
+      for (uint32_t j = 128 + lane; j < nuse; j += 64) {
         uint32_t g, p;
         const uint32_t w = item(j, &g, &p);
         const uint32_t rl = w >> 24;
@@ -565,37 +669,244 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       const uint32_t inc = wave_scan_incl(cnum);
       const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
       base_l[lane] = inc - cnum;
-      cnt_l[lane] = 0;  // now the arrival counter of the read
       const uint64_t base = region0 + used;
       const bool fits = spill_ok && used + total <= region;
       if (lane == 0) {
-        tbase[wt] = (uint32_t)base;
-        tcount2[wt] = fits ? total : 0u;
+        tbase[wt_prev] = (uint32_t)base;
+        tcount2[wt_prev] = fits ? total : 0u;
       }
       wave_lds_sync();
       if (fits && total) {
-        for (uint32_t j = lane; j < nuse; j += 64) {
-          uint32_t g, p;
-          const uint32_t w = item(j, &g, &p);
-          const uint32_t rl = w >> 24, v = w & 0xFFFFu;
-          const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
-          if (v > thr) continue;
-          const uint32_t ord = atomicAdd(&cnt_l[rl], 1u);
-          stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt * WT + rl), g, p, v);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          if (kw[q] != NX_REJECT) {
+            const uint32_t rl = kw[q] >> 24;
+            stage[base + base_l[rl] + ko[q]] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), kg[q], kp[q], kw[q] & 0xFFFFu);
+          }
+        }
+        if (nuse > 128) {
+          for (uint32_t j = 128 + lane; j < nuse; j += 64) {
+            uint32_t g, p;
+            const uint32_t w = item(j, &g, &p);
+            const uint32_t rl = w >> 24, v = w & 0xFFFFu;
+            const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
+            if (v > thr) continue;
+            // places of the later rounds: behind the first two rounds' tuples of the read, counted down from its total
+            const uint32_t ord = atomicAdd(&cnt_l[rl], 0xFFFFFFFFu) - 1u;
+            stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), g, p, v);
+          }
         }
       }
       wave_lds_sync();
-      best_l[lane] = 0xFFFFFFFFu;  // for the next wave-tile
+      best_l[lane] = 0xFFFFFFFFu;  // for the wave-tile after next
       used += total;
       nrep += lane == 0 ? nl : 0u;
-      par ^= 1u;
-      rec_cur = rec_nx;
-      rec_nx = rec_pre;
-      valid_cur = valid_nx;
-      xw_cur = xw_nx;
-      wave_lds_sync();  // the next wave-tile rewrites the records, the candidate list and cnt / base
+    };
+    // everything that is left of prev: the pass over its first 64 overflow entries (fetched a window
+    // ago, or -- fresh -- right before this call), the rest of them, phase D
+    auto finish_prev = [&]() __attribute__((always_inline)) {
+      entry_compare(par ^ 1u, nlist_prev, ulen_prev, o_n, o_k, o_seg, o_meta, o_xw, o_rec, o_a, o_b, o_d);
+      PF(6)
+      overflow_rest_prev();
+      wave_lds_sync();
+      phase_d_prev();
+      PF(7)
+    };
+
+    uint4 cpv = make_uint4(0, 0, 0, 0);
+    uint32_t cpm = 0, cpd = 0;
+    uint32_t nlist = 0;           // reported candidates of cur so far (wave-uniform)
+    uint32_t best = 0xFFFFFFFFu;  // smallest mismatch count reported for this lane's read by the in-lane comparisons
+    uint32_t ulen = 0xFFFFFFFFu, total_cur = 0;
+    uint32_t wc[W], oc[W], ovf[W];  // accepted pairs of (window, this lane's read); entries beyond the third of this lane's probe of window k, and where in E
+    uint32_t meta_nx = 0, xw_nx = 0, bb_nx[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) wc[k] = oc[k] = ovf[k] = 0, bb_nx[k] = WB_NONE;
+
+    if (have_cur) {
+      pcopy_begin(wt, cpv, cpm, cpd);
+      const bool active = wt * WT + lane < n;
+      // this wave-tile's per-read state: registers of the read's lane; the meta word and the xpos word
+      // also go to LDS, where the overflow entries pick up their reads'
+      const int rlen = (int)REC_LEN(meta_cur);
+      const uint32_t budget = REC_BUDGET(meta_cur), valid_cur = REC_VALID(meta_cur);
+      s_meta[par][wid][lane] = meta_cur;
+      if constexpr (RX) s_xp[par][wid][lane] = xw_cur;
+      // every read of the wave-tile of one length: the comparisons use scalar length masks
+      const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(rlen);
+      ulen = __ballot(active && (uint32_t)rlen != len0) == 0 ? len0 : 0xFFFFFFFFu;
+
+      // a reported candidate of the lane's own read (in-lane comparisons): appended in lane order
+      auto report_own = [&](uint32_t w, uint32_t gene, uint32_t pos, uint32_t& wck) __attribute__((always_inline)) {
+        const bool acc = w != NX_REJECT;
+        wck += acc ? 1u : 0u;
+        const bool rep = acc && !(w & NX_DUP);
+        const unsigned long long vote = __ballot(rep);
+        if (vote == 0) return;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
+        const uint32_t slot = nlist + below;
+        nlist += (uint32_t)__popcll(vote);
+        if (!rep) return;
+        const uint32_t v = w & 0xFFFFu;
+        best = v < best ? v : best;
+        if (slot < MATCHT_WLIST) {
+          s_list[par][wid][slot] = make_uint3(w, gene, pos);
+        } else if (slot - MATCHT_WLIST < sregion) {
+          spill[sregion0 + (slot - MATCHT_WLIST)] = make_uint4(w, gene, pos, 0u);
+        }
+      };
+
+      // (a generic lambda over the window number: the window loop must be unrolled for the per-window
+      // registers to stay registers, and past a certain size the unroller gives up on a plain loop)
+      auto window = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const int q1 = win[k];
+        const uint32_t sh = 2u * (uint32_t)(CL - q1);
+        WinTab tb;  // (its scalar loads are in flight while the wave waits for the window's lines)
+        win_tab(ulen, k, sh, (uint32_t)rlen, tb);
+        // ---- arrival: the quads write the lines they fetched into the line buffer (swizzled) ...
+        {
+          const uint32_t q = lane >> 2;
+          const uint32_t sw = ((q >> 1) & 7u) ^ (q & 1u);
+          const uint32_t wb0 = q * 8u + ((2u * part) ^ sw);  // in units of 16 bytes; the line's second half: ^ 1
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++) {
+            line_l[rr * 128 + wb0] = va[rr];
+            line_l[rr * 128 + (wb0 ^ 1u)] = vb[rr];
+          }
+        }
+        PF(0)
+        // ---- ... and with nothing left in flight: the loads of prev's overflow entries (used after the
+        // next wait; with one window per wave-tile, at once), then the ring is refilled with the next
+        // window (this wave-tile's, or the next one's first; the records of the wave-tile after that
+        // follow the last refill).  Whatever is consumed from here to the next arrival was loaded
+        // before the wait that has just ended.
+        if (k == 0 && have_prev) entry_fetch();
+        if (W == 1) {
+          if (have_prev) finish_prev();
+          if (have_next) phase_a_all(wt + nw, par ^ 1u, rec_nx, meta_nx, xw_nx, bb_nx);
+          wave_lds_sync();
+        }
+        if (k + 1 < W) {
+          issue_window(bb_cur[k + 1 < W ? k + 1 : 0], va, vb);
+        } else {
+          if (have_next) issue_window(bb_nx[0], va, vb);
+          if (wt + 2 * nw < nwt) fetch(wt + 2 * nw, rec_nx);
+        }
+        PF(1)
+        wave_lds_sync();
+        // ---- lane p takes line p: its header now, an entry's context when its turn comes (the line
+        // buffer stays as it is until the next arrival)
+        const uint32_t rb = lane * 8u + (((lane >> 1) & 7u) ^ (lane & 1u));
+        const uint4 h0 = line_l[rb], h1 = line_l[rb ^ 1u];
+        const uint32_t cnt = h0.x;
+        ncand += cnt;
+        oc[k] = cnt > CTX_INLINE ? cnt - CTX_INLINE : 0u;
+        ovf[k] = h0.y;
+        novf += oc[k];
+        PF(2)
+        // the next wave-tile's records arrived with this wave-tile's first lines: its phase A
+        if (W > 1 && k == 0 && have_next) phase_a_all(wt + nw, par ^ 1u, rec_nx, meta_nx, xw_nx, bb_nx);
+        PF(8)
+        // prev's overflow entries arrived with this window's lines: their pass, the rest of prev
+        if (W > 1 && k == 1 && have_prev) finish_prev();
+        if (k + 1 == W) {
+          // ---- this wave-tile's overflow entries: the first 64 are listed (s_oix: where in E) and their
+          // lanes take the reads' meta / xpos words and records along; the loads follow when the
+          // next wave-tile's first window has arrived
+          uint32_t pre[W], total = 0;
+#pragma unroll
+          for (int kk = 0; kk < W; kk++) {
+            const uint32_t inc = wave_scan_incl(oc[kk]);
+            pre[kk] = total + inc - oc[kk];
+            total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+          }
+#ifdef MUSC_LANE_DBG
+          if (MUSC_LANE_DBG & 4) total = 0;
+#endif
+          total_cur = total;
+          owner_tables(0, oc, ovf, pre);
+          o_n = total < (uint32_t)WT ? total : (uint32_t)WT;
+          const uint32_t probe = lane < o_n ? (uint32_t)s_own[wid][lane] : 0u;
+          o_k = probe >> 6;
+          o_seg = probe & 63u;
+          o_meta = s_meta[par][wid][o_seg];
+          if constexpr (RX) o_xw = s_xp[par][wid][o_seg];
+          rec_of(par, o_seg, o_rec);
+        }
+        wave_lds_sync();
+        PF(3)
+        // ---- the read's image for this window, then the line's three entries, in this lane
+        uint32_t img[8], xm[8];
+        {
+          Rec<RW> rec;
+          rec_of(par, lane, rec);
+          read_image<RW>(rec, sh, img);
+        }
+        x_mask(xw_cur, sh, xm);
+        uint4 ca = line_l[rb ^ 2u], cb = line_l[rb ^ 3u];
+        PF(9)
+#pragma unroll
+        for (int s = 0; s < CTX_INLINE; s++) {
+#ifdef MUSC_LANE_DBG
+          const bool live = (uint32_t)s < cnt && !(MUSC_LANE_DBG & 1);
+#else
+          const bool live = (uint32_t)s < cnt;
+#endif
+          if (!__any(live)) break;
+          uint4 na = ca, nb = cb;
+          if (s + 1 < CTX_INLINE) {  // the next entry's context is on its way while this one is compared
+            na = line_l[rb ^ (uint32_t)(2 * s + 4)];
+            nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
+          }
+          const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
+          const uint32_t jx = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
+          const uint32_t c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+          const uint32_t w = score(live, k, q1, img, tb, xm, jx, c, rlen, budget, valid_cur, lane);
+          report_own(w, gene, jx - (uint32_t)q1, wc[k]);
+          ca = na;
+          cb = nb;
+        }
+        PF(4)
+      };
+      window(std::integral_constant<int, 0>{});
+      if constexpr (W > 1) window(std::integral_constant<int, 1>{});
+      if constexpr (W > 2) window(std::integral_constant<int, 2>{});
+      if constexpr (W > 3) window(std::integral_constant<int, 3>{});
+#ifdef MUSC_LANE_PROF
+      pf_tiles++;
+#endif
+    } else {
+      // past this wave's last wave-tile: prev's overflow entries and its phase D are all that is left
+      entry_fetch();
+      finish_prev();
     }
+    wave_lds_sync();
+    if (have_cur) pcopy_end(cpv, cpm, cpd);
+    // ---- cur becomes prev
+    have_prev = have_cur;
+    if (have_cur) {
+      wt_prev = wt;
+      nlist_prev = nlist;
+      best_prev = best;
+      ulen_prev = ulen;
+      total_prev = total_cur;
+#pragma unroll
+      for (int k = 0; k < W; k++) wc_prev[k] = wc[k], bb_prev[k] = bb_cur[k], bb_cur[k] = bb_nx[k], oc_prev[k] = oc[k], ovf_prev[k] = ovf[k];
+      meta_cur = meta_nx;
+      xw_cur = xw_nx;
+      par ^= 1u;
+      wt += nw;
+    }
+    wave_lds_sync();  // the next wave-tile rewrites cnt / base
+    PF(5)
   }
+#ifdef MUSC_LANE_PROF
+  if ((gw == 0 || gw == 1001) && (threadIdx.x & 63) == 0 && pf_tiles > 4)
+    printf("wave %u: %u tiles, cycles/tile: total %llu | arrive(wait+lds write) %llu issue %llu hdr %llu phA %llu finish_prev(epass %llu rest+phD %llu) expand %llu img %llu slots %llu end %llu\n", gw, pf_tiles,
+           (__builtin_amdgcn_s_memtime() - pstart) / pf_tiles, pf[0] / pf_tiles, pf[1] / pf_tiles, pf[2] / pf_tiles, pf[8] / pf_tiles,
+           pf[6] / pf_tiles, pf[7] / pf_tiles, pf[3] / pf_tiles, pf[9] / pf_tiles, pf[4] / pf_tiles, pf[5] / pf_tiles);
+#endif
   if (pcopy) {
     for (; wt < pnwt; wt += nw) {
       uint4 cpv = make_uint4(0, 0, 0, 0);

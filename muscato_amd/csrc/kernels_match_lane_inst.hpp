@@ -5,7 +5,8 @@
 #ifndef MATCHT_WAVES
 #define MATCHT_WAVES 2  // waves per SIMD the register allocator leaves room for (256 VGPRs)
 #endif
-template <int RW, int W>
+#define MATCHT_WLIST 96  // reported candidates of a wave-tile kept in LDS (cfg3: ~53); more spill to HBM
+template <int RW, int W, bool RX>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
@@ -25,7 +26,11 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
    uint64_t, uint4*, uint64_t, uint32_t*, uint32_t*, int, uint32_t, uint32_t*, unsigned long long*, const uint4*,   \
    const uint32_t*, const uint32_t*, uint32_t, uint4*, uint64_t, const uint32_t*)
 #define MUSC_LANE_INSTANCES(X, RW) \
-  X template __global__ void k_match_t<RW, 1> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 2> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 3> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 4> MUSC_LANE_ARGS;
+  X template __global__ void k_match_t<RW, 1, false> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 2, false> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 3, false> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 4, false> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 1, true> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 2, true> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 3, true> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 4, true> MUSC_LANE_ARGS;

@@ -1073,8 +1073,10 @@ int musc_reads_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t*
 // start over with larger buffers), later passes run without host round trips and check the
 // guards once at the end -- the same protocol as the two-kernel path below.
 extern "C++" {
-static size_t match_dyn_lds(int W, int block_mode) {
-  return block_mode ? (size_t)TILE * W * 4 + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;  // TILE = 4 waves x 64
+static size_t match_dyn_lds(int kind, int W, int block_mode) {
+  // per-(window, read) counters of the wave-tile in hand (k_match_t: of two wave-tiles), then (mode 1) the sketch
+  const size_t wcnt = (size_t)TILE * W * 4 * (kind == MK_LANE ? 2 : 1);  // TILE = 4 waves x 64
+  return block_mode ? wcnt + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;
 }
 
 // the kernel a pass launches, as a function pointer (occupancy queries and attributes)
@@ -1083,7 +1085,7 @@ static const void* match_fn(const musc_ctx* c, int W) {
   const int kind = match_kind(c, W);
   const bool rx = c->reads_have_x;
   if (kind == MK_LANE) {
-#define MUSC_LANE_FN(WN) reinterpret_cast<const void*>(&k_match_t<RW, WN>)
+#define MUSC_LANE_FN(WN) (rx ? reinterpret_cast<const void*>(&k_match_t<RW, WN, true>) : reinterpret_cast<const void*>(&k_match_t<RW, WN, false>))
     switch (W) {
       case 1: return MUSC_LANE_FN(1);
       case 2: return MUSC_LANE_FN(2);
@@ -1103,7 +1105,7 @@ static const void* match_fn(const musc_ctx* c, int W) {
 template <int RW>
 static unsigned match_resident(musc_ctx* c, int W, int block_mode) {
   int per_cu = 0, ncu = 0;
-  const size_t lds = match_dyn_lds(W, block_mode);
+  const size_t lds = match_dyn_lds(match_kind(c, W), W, block_mode);
   const void* fn = match_fn<RW>(c, W);
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TILE, lds);
   if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
@@ -1131,10 +1133,10 @@ template <int RW>
 static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_mode, uint32_t block_thr,
                          unsigned ngrid, int set = 0, uint32_t prev_tiles = 0) {
   const dim3 grid(ngrid), block(TILE);
-  const size_t lds = match_dyn_lds(W, block_mode);
+  const int kind = match_kind(c, W);
+  const size_t lds = match_dyn_lds(kind, W, block_mode);
   DevBuf<uint4>& st = set ? c->stage_b : c->stage;
   DevBuf<uint32_t>& tc = set ? c->tcount2_b : c->tcount2;
-  const int kind = match_kind(c, W);
 #define MUSC_LAUNCH_MATCH(K, ...)                                                                                 \
   hipLaunchKernelGGL(K, grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,                       \
                      c->ctx_T, c->ctx_E, st.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,          \
@@ -1147,7 +1149,8 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
     const uint32_t* const rdx = c->reads_have_x ? (const uint32_t*)c->rdx.p : (const uint32_t*)nullptr;
     if (kind == MK_LANE) {
 #define MUSC_LAUNCH_LANE(WN)                                                                                 \
-      MUSC_LAUNCH_MATCH((k_match_t<RW, WN>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
+      if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, true>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
+      else MUSC_LAUNCH_MATCH((k_match_t<RW, WN, false>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
       switch (W) {
         case 1: MUSC_LAUNCH_LANE(1); break;
         case 2: MUSC_LAUNCH_LANE(2); break;
@@ -1966,12 +1969,21 @@ std::mutex g_rccl_mu;
 RcclApi* rccl_api() {
   static RcclApi api;
   if (api.lib || !api.err.empty()) return &api;
-  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+  // MUSC_RCCL_LIB names the library (tests point it at a missing file); otherwise the one next to the
+  // HIP runtime this library links against, then whatever the loader finds
+  std::string first_err;
+  std::vector<std::string> names;
+  if (const char* e = getenv("MUSC_RCCL_LIB")) names.push_back(e);
+  else names = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  for (const std::string& name : names) {
+    (void)dlerror();
+    api.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (api.lib) break;
+    const char* e = dlerror();  // (one call: it returns the message and clears it)
+    if (first_err.empty()) first_err = e ? e : "not found";
   }
   if (!api.lib) {
-    api.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+    api.err = std::string("cannot load librccl: ") + first_err;
     return &api;
   }
 #define MUSC_RCCL_SYM(FIELD, NAME)                                   \
@@ -1988,6 +2000,16 @@ RcclApi* rccl_api() {
   return &api;
 }
 }  // namespace
+
+int musc_rccl_probe(char* msg, uint64_t cap) {
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  RcclApi* api = rccl_api();
+  if (msg && cap) {
+    strncpy(msg, api->err.c_str(), cap - 1);
+    msg[cap - 1] = 0;
+  }
+  return api->err.empty() ? 0 : 20;
+}
 
 __global__ void k_rebase_reads(uint4* __restrict__ h, uint64_t n, uint32_t base) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) h[i].x += base;

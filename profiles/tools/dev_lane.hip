@@ -16,4 +16,7 @@
 #define DEV_W 2
 #endif
 #include "../../muscato_amd/csrc/kernels_match_lane_inst.hpp"
-template __global__ void k_match_t<DEV_RW, DEV_W> MUSC_LANE_ARGS;
+#ifndef DEV_RX
+#define DEV_RX false
+#endif
+template __global__ void k_match_t<DEV_RW, DEV_W, DEV_RX> MUSC_LANE_ARGS;

@@ -66,3 +66,18 @@ def test_every_entry_point_has_matching_argtypes():
             assert is_ptr == bound_ptr, "%s: `%s` bound as %s" % (name, decl, ct)
             if not is_ptr and "uint64_t" in decl:
                 assert ctypes.sizeof(ct) == 8, "%s: `%s` bound as a %d-byte integer" % (name, decl, ctypes.sizeof(ct))
+
+
+def test_rccl_probe_reports_a_missing_library():
+    """rccl_api() called dlerror() twice (the second call returns NULL) and built a
+    std::string from it.  With the loader pointed at a file that does not exist the probe must come
+    back with code 20 and the loader's message -- in a process of its own, the lookup is cached."""
+    import subprocess
+    import sys
+    code = ("import ctypes\nfrom muscato_amd import _lib\nlib = _lib.load()\nbuf = ctypes.create_string_buffer(256)\n"
+            "rc = lib.musc_rccl_probe(buf, 256)\nprint(rc, buf.value.decode())\n")
+    env = dict(os.environ, MUSC_RCCL_LIB="/nonexistent/librccl.so.1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert rc == "20" and "cannot load librccl" in msg and "nonexistent" in msg
