@@ -585,12 +585,12 @@ def main() -> int:
             ach = (b_m / 1e9) / (ms_m / 1e3) if ms_m > 0 else 0.0
             ach_s = (b_s / 1e9) / (ms_m / 1e3) if ms_m > 0 else 0.0
             nlm = max(st["match_launches"], 1)
-            # which of the two kernels ran (match_dense in muscato_hip.hip): k_match_d for up to two windows
-            dense = len(wl.windows) <= 2 and wl.read_len <= 112 and os.environ.get("MUSC_MATCH") != "quad"
-            kname = "k_match_d" if dense else "k_match"
+            # which of the two kernels ran (match_kind in muscato_hip.hip): k_match_t unless MUSC_MATCH=quad
+            lane = os.environ.get("MUSC_MATCH") != "quad"
+            kname = "k_match_t" if lane else "k_match"
             fused_note = ("from the second launch of a pass on, a launch also moves the previous batch's staged tuples "
                           "into the hit list (32 B of traffic per tuple), which `achieved` does not bill"
-                          if dense and st["match_launches"] > 1 else None)
+                          if lane and st["match_launches"] > 1 else None)
             match_roof = {
                 "kernel": kname + " (screen + confirm + per-read selection, context buckets)", "bound": "hbm",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -626,7 +626,7 @@ def main() -> int:
                                 + ", repeat passes over the same reads (no sizing round trips); SURVEY 8d's "
                                   "pinned-host-to-pinned-host scope is `survey_scope`, a pass over fresh reads `first_pass_ms`",
             },
-            "index": {"kind": "context buckets (128 B, fused k_match_d / k_match)" if kind == 1 else "64-byte buckets (k_screen -> k_confirm)",
+            "index": {"kind": "context buckets (128 B, fused k_match_t)" if kind == 1 else "64-byte buckets (k_screen -> k_confirm)",
                       "bytes": st["index_bytes"]},
             "roofline": dominant, "roofline_confirm": confirm_roof, "roofline_screen": screen_roof,
             "per_step": {

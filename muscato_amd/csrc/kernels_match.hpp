@@ -806,6 +806,52 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Reads with X on context buckets (k_match_t, RX): with an X-free database an X in a read is a mismatch wherever
+// the read is placed, and a window holding one never finds its key in the index.  What the kernel
+// needs of a read's X is where they are: xpos = up to four positions (7 bits each, bits 0-27) and
+// their number (bits 28-31, saturating at 15).  A read with more than four X takes part only if
+// that many mismatches exceed its budget anyway -- then it has no tuples at all (k_xpos_check
+// makes the run take the two-kernel path otherwise).
+#define XPOS_MAX 4
+#define XPOS_CNT(w) ((w) >> 28)
+#define XPOS_AT(w, q) (((w) >> (7 * (q))) & 127u)
+
+MUSC_KERNEL void k_read_xpos(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm, uint64_t nreads, int rw,
+                            uint32_t* __restrict__ xpos) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  uint32_t w = 0;
+  if (rd[(i + 1) * rw - 1] & READ_HAS_X) {
+    uint32_t cnt = 0;
+    for (int j = 0; j < rw - 1; j++) {
+      uint32_t m = rdm[i * rw + j] & 0x55555555u;
+      while (m) {
+        const uint32_t b = (uint32_t)__ffs(m) - 1u;
+        m &= m - 1u;
+        const uint32_t p = 16u * (uint32_t)j + (b >> 1);
+        if (cnt < XPOS_MAX && p < 128u) w |= p << (7u * cnt);
+        cnt++;
+      }
+    }
+    w |= (cnt > 15u ? 15u : cnt) << 28;
+  }
+  xpos[i] = w;
+}
+
+// *bad = 1 if some read holds more than XPOS_MAX X and that many mismatches are within its budget
+MUSC_KERNEL void k_xpos_check(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ xpos, uint64_t nreads, int rw,
+                             const uint16_t* __restrict__ nmiss_tab, uint32_t max_len, uint32_t* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  const uint32_t cnt = XPOS_CNT(xpos[i]);
+  if (cnt <= XPOS_MAX) return;
+  const uint32_t len = rd[(i + 1) * rw - 1] & 0xFFFFu;
+  const uint32_t budget = len <= max_len ? nmiss_tab[len] : 0xFFFFu;
+  if (cnt == 15u || cnt <= budget) atomicOr(bad, 1u);
+}
+
+
 // k_compact_w -- hits[counters[2] + tpre[wt] ...] = the wave-tile's staged tuples (tpre = scan of
 // tcount2), a wave per wave-tile: plain 16-byte copies, contiguous on both sides.
 MUSC_KERNEL __launch_bounds__(256) void k_compact_w(uint32_t nwt, const uint32_t* __restrict__ tbase,

@@ -1,13 +1,13 @@
 // k_match_t -- the fused screen + confirm + select kernel on context buckets with the comparisons done
 // IN THE LANE THAT OWNS THE READ (device code; compiled in match_lane_rw*.hip, declared in
-// kernels_match_lane_inst.hpp; shares the bucket layout, parameter block, fit rules, cdiff and tuple
-// staging protocol of kernels_match.hpp / kernels_match_dense.hpp).
+// kernels_match_lane_inst.hpp; shares the bucket layout, parameter block and fit rules of
+// kernels_match.hpp).
 //
-// k_match compares where a bucket line arrives (a quad of lanes per probe) and k_match_d moves the
-// entries that exist onto a stack in LDS and pops 64 of them per comparison pass.  Both spend most
-// of their instructions on getting an entry and "its" read into the same lane: DPP moves, votes,
-// stack writes, per-entry record reads and funnel shifts, owner tables -- 2 640 instructions per
-// wave-tile for 237 comparisons that need about 50 instructions each.  Here the bucket line is
+// k_match compares where a bucket line arrives (a quad of lanes per probe); round 2's k_match_d
+// moved the entries that exist onto a stack in LDS and popped 64 of them per comparison pass.  Both
+// spend most of their instructions on getting an entry and "its" read into the same lane: DPP moves,
+// votes, stack writes, per-entry record reads and funnel shifts, owner tables -- 2 640 instructions
+// per wave-tile for 237 comparisons that need about 50 instructions each.  Here the bucket line is
 // TRANSPOSED instead: the quad that fetched a line (coalesced: 32 bytes per lane) writes it into a
 // per-wave line buffer in LDS as it arrived, and once the 64 lines of a window are there, lane p
 // reads line p -- all 128 bytes, eight ds_read_b128 -- into its own registers, where the read's
@@ -33,15 +33,19 @@
 //     wave-tile's first), which is what the next wait is for anyway;
 //   * nothing else is waited for fresh: the records of wave-tile t + 1 are fetched behind the last
 //     refill of tile t - 1 and used after the first wait of tile t; the entries beyond a bucket's
-//     third (CtxEntry in E, 10 % of the entries walked on cfg3) are loaded behind the last window's
-//     lines of tile t, a lane per entry, and compared after the first wait of tile t + 1; tile t's
-//     per-read selection (phase D) follows that pass, so records and candidate lists are
-//     double-buffered;
+//     third (CtxEntry in E, 10 % of the entries walked on cfg3) are listed when tile t's last window
+//     has arrived (a lane per entry, which takes the read's record along), LOADED right after the
+//     first wait of tile t + 1 -- nothing is in flight then, so the compiler has no reason to wait
+//     for anything -- and compared after tile t + 1's second wait; tile t's per-read selection
+//     (phase D) follows that pass, so the candidate lists are double-buffered;
+//   * loads go straight into the registers their consumer reads (a load under a branch, or one
+//     whose result is re-packed, becomes "load into a temporary, wait, copy");
 //   * and no register spills: a scratch reload is a vector load whose wait drains the ring.
 // A wave thus alternates "64 lines in flight" with "compare a window": with two waves per SIMD one
 // computes while the other waits.
 //
-// LDS per workgroup of four waves: 4 x 17.4 KB + the MaxMatches sketch = 78 KB: two workgroups per CU.
+// LDS per workgroup of four waves: 4 x 16.2 KB + the MaxMatches sketch = 73 KB: two workgroups per CU
+// (registers: ~230 of the 256 two waves per SIMD may use).
 #pragma once
 #include "kernels_match_lane_inst.hpp"
 
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   };
 
   // The tuples the PREVIOUS batch's launch staged (pstage != nullptr: same grid, same regions, the
-  // other stage buffer) move to their final place in `hits` from inside this launch (as in k_match_d)
+  // other stage buffer) move to their final place in `hits` from inside this launch (the protocol of match_ctx_pass)
   bool pcopy = pstage != nullptr;
   unsigned long long pbase = 0;
   if (pcopy) {
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         entry_compare(pp, nlist_prev, ulen_prev, cnt, ek, seg, tmeta, txw, trec, ta, tb2, td);
       }
     };
-    // phase D for prev: per-read selection and the tuples (as in k_match_d)
+    // phase D for prev: per-read selection and the tuples (the protocol of match_ctx_pass)
     auto phase_d_prev = [&]() __attribute__((always_inline)) {
 #ifdef MUSC_LANE_DBG
       if (MUSC_LANE_DBG & 8) return;

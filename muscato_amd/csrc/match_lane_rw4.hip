@@ -7,7 +7,6 @@
 #include "kernels_index.hpp"
 #include "kernels_screen.hpp"
 #include "kernels_match.hpp"
-#include "kernels_match_dense.hpp"
 #include "kernels_match_lane.hpp"
 #include "kernels_match_lane_inst.hpp"
 MUSC_LANE_INSTANCES(, 4)

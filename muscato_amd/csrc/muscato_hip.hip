@@ -41,7 +41,6 @@
 #include "kernels_screen.hpp"
 #include "kernels_confirm.hpp"
 #include "kernels_match.hpp"
-#include "kernels_match_dense.hpp"
 #include "kernels_match_lane_inst.hpp"  // k_match_t: declaration only (defined in match_lane_rw*.hip)
 MUSC_LANE_INSTANCES(extern, 4)
 MUSC_LANE_INSTANCES(extern, 8)
@@ -131,7 +130,7 @@ struct musc_ctx {
   uint32_t* dbm2 = nullptr;  // null when the database holds no X (or an all-zero plane made for reads that do)
   bool db_has_x = false;     // the database holds an X
   bool reads_have_x = false; // some loaded read holds an X
-  // reads with X on context buckets (k_match_d<.., RX>): where each read's X are (k_read_xpos), and
+  // reads with X on context buckets (k_match_t<.., RX>): where each read's X are (k_read_xpos), and
   // whether the reads in hand fit that form under a given mismatch budget (k_xpos_check), cached
   DevBuf<uint32_t> rdx;
   uint64_t rdx_epoch = ~0ull;
@@ -188,7 +187,7 @@ struct musc_ctx {
   hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_join = nullptr;
   DevBuf<uint32_t> scan_tmp, tcount2, tpre;
   DevBuf<uint4> stage;
-  // k_match_d moves the tuples a batch staged from inside the NEXT batch's launch: a second set
+  // k_match_t moves the tuples a batch staged from inside the NEXT batch's launch: a second set
   DevBuf<uint32_t> tcount2_b, tpre_b;
   DevBuf<uint4> stage_b;
   DevBuf<uint32_t> p_nx;
@@ -872,14 +871,14 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
 }
 
 // Which of the kernels on context buckets runs: k_match_t (comparisons in the lane that owns the read,
-// kernels_match_lane.hpp) by default; MUSC_MATCH=dense selects k_match_d (dense comparison passes,
-// kernels_match_dense.hpp: at most two windows, records of at most eight words) and MUSC_MATCH=quad
-// k_match (comparison where the line arrives) -- the two earlier kernels, kept for A/B runs.
-enum MatchKind { MK_QUAD = 0, MK_DENSE = 1, MK_LANE = 2 };
+// kernels_match_lane.hpp); MUSC_MATCH=quad selects k_match (comparison where the line arrives), the
+// first fused kernel, kept as a second implementation the tests run everything through as well.
+enum MatchKind { MK_QUAD = 0, MK_LANE = 2 };
 static int match_kind(const musc_ctx* c, int W) {
+  (void)c;
+  (void)W;
   const char* e = getenv("MUSC_MATCH");
   if (e && !strcmp(e, "quad")) return MK_QUAD;
-  if (e && !strcmp(e, "dense")) return (W <= 2 && c->rw <= 8) ? MK_DENSE : MK_QUAD;
   return MK_LANE;
 }
 
@@ -927,7 +926,7 @@ static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
 // Which index a run with these parameters and reads of at most max_len bases uses: context
 // buckets when every read fits their 120 bases of context around each of at most CTX_MAX_W
 // windows, the database holds no X (the context has no mask plane; reads may hold some where
-// k_match_d runs, see reads_x_fit) and positions fit 32 bits.
+// k_match_t runs, see reads_x_fit) and positions fit 32 bits.
 static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL) {
   if (const char* e = getenv("MUSC_INDEX"))
     if (strcmp(e, "classic") == 0) return false;
@@ -935,7 +934,7 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
   // none when the other side does, and the database's stays for the context's lifetime)
   if (c->db_has_x) return false;
   if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
-  // reads with X: k_match_t / k_match_d handle them, and only while every read either lists all its X
+  // reads with X: k_match_t handles them, and only while every read either lists all its X
   // in its xpos word or has more X than mismatches allowed (reads_x_fit, cached per reads + budget)
   if (c->reads_have_x && !(match_kind(c, P->n_windows) != MK_QUAD && reads_x_fit(c, P, max_len))) return false;
   if (P->n_windows > CTX_MAX_W) return false;
@@ -1094,10 +1093,6 @@ static const void* match_fn(const musc_ctx* c, int W) {
     }
 #undef MUSC_LANE_FN
   }
-  if constexpr (RW <= 8) {
-    if (kind == MK_DENSE)
-      return rx ? reinterpret_cast<const void*>(&k_match_d<RW, true, true>) : reinterpret_cast<const void*>(&k_match_d<RW, true, false>);
-  }
   return W <= 2 ? reinterpret_cast<const void*>(&k_match<RW, true>) : reinterpret_cast<const void*>(&k_match<RW, false>);
 }
 
@@ -1158,11 +1153,6 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
         default: MUSC_LAUNCH_LANE(4); break;
       }
 #undef MUSC_LAUNCH_LANE
-      return;
-    }
-    if constexpr (RW <= 8) {
-      if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_d<RW, true, true>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx);
-      else MUSC_LAUNCH_MATCH((k_match_d<RW, true, false>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx);
       return;
     }
   }
@@ -1269,7 +1259,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
           return rc;
         HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
       }
-      // A pass of k_match_d over several batches: the tuples batch b staged are moved into
+      // A pass of k_match_t over several batches: the tuples batch b staged are moved into
       // `hits` by the launch of batch b + 1 (other staging set, same grid so the same regions);
       // only the last batch needs k_compact_w.
       const bool more = r0 + n < c->nreads;

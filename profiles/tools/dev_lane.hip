@@ -7,7 +7,6 @@
 #include "../../muscato_amd/csrc/kernels_index.hpp"
 #include "../../muscato_amd/csrc/kernels_screen.hpp"
 #include "../../muscato_amd/csrc/kernels_match.hpp"
-#include "../../muscato_amd/csrc/kernels_match_dense.hpp"
 #include "../../muscato_amd/csrc/kernels_match_lane.hpp"
 #ifndef DEV_RW
 #define DEV_RW 8

@@ -49,7 +49,7 @@ def test_baseline_config_at_full_size(name, index, monkeypatch):
     "classic" forces the latter for cfg3 as well."""
     import torch
     monkeypatch.delenv("MUSC_MATCH", raising=False)
-    if index == "quad":  # context buckets with k_match instead of k_match_d
+    if index == "quad":  # context buckets with k_match instead of k_match_t
         monkeypatch.setenv("MUSC_MATCH", "quad")
         monkeypatch.delenv("MUSC_INDEX", raising=False)
     elif index == "classic":
@@ -119,7 +119,7 @@ def test_baseline_config_at_full_size(name, index, monkeypatch):
         assert NT < (1 << 24) and TL <= (1 << 10) and U < (1 << 26)
         skey = torch.sort(key).values
         assert bool((skey[1:] != skey[:-1]).all()), "the union over windows is not a set"
-        # the same pass again: sized now (no host round trips; with k_match_d the tuples of a batch
+        # the same pass again: sized now (no host round trips; with k_match_t the tuples of a batch
         # are moved into place by the next batch's launch) -- the same list, tuple for tuple
         assert eng.match_device(cfg, apply_mmtol=False) == n_all
         st2 = eng.stats()

@@ -500,7 +500,7 @@ def test_block_screening_falls_back_to_exact_counters(eng):
 def test_index_selection(monkeypatch):
     """Which index a run gets (ensure_index): context buckets + the fused kernel when every read
     fits 120 bases of context around each of at most four windows and the database holds no X (reads
-    may, where k_match_d runs); the 64-byte buckets and k_screen -> k_confirm otherwise -- with
+    may); the 64-byte buckets and k_screen -> k_confirm otherwise -- with
     identical tuples either way."""
     from muscato_amd import Config, Engine, sorted_hits
     monkeypatch.delenv("MUSC_INDEX", raising=False)
