@@ -484,18 +484,31 @@ def main() -> int:
             packed_dev = pack2bit_device(reads)
             h_packed = torch.empty(packed_dev.shape, dtype=torch.uint8, pin_memory=True)
             h_packed.copy_(packed_dev)
-            h_off = torch.empty(n_loaded + 1, dtype=torch.int64, pin_memory=True)
-            h_off.copy_(torch.arange(0, n_loaded + 1, dtype=torch.int64) * wl.read_len)
             del packed_dev
+            # tuples come down in the compact form (a u32 word gene | pos | nmiss per tuple + a count byte per
+            # read: the list is read-major) where the fields fit, else as 16-byte tuples
+            budget = int((1.0 - wl.pmatch) * wl.read_len)
+            cbits = [max(1, (wl.n_targets - 1).bit_length()), max(1, wl.target_len.bit_length()), max(1, budget.bit_length())]
+            compact = sum(cbits) <= 32
+            h_words = torch.empty(nmax, dtype=torch.int32, pin_memory=True)
+            h_counts = torch.empty(n_loaded + 8, dtype=torch.uint8, pin_memory=True)
             torch.cuda.synchronize()
             times = []
             for rep in range(3):
                 t1 = time.perf_counter()
-                eng.load_reads_packed_ptr(h_packed.data_ptr(), 0, h_off.data_ptr(), n_loaded)
+                # the upload is queued in pieces on a copy stream; the sizing pass below packs and
+                # matches each batch as its pieces arrive
+                eng.load_reads_packed32_ptr(h_packed.data_ptr(), 0, 0, wl.read_len, n_loaded, async_upload=True)
                 t_up = time.perf_counter()
                 n = match()
                 t_m = time.perf_counter()
-                if n:
+                if n and compact:
+                    try:
+                        eng.hits_to_compact(h_words.data_ptr(), nmax, h_counts.data_ptr(), n_loaded + 8, False, cbits)
+                    except Exception as e:  # a read with more than 255 tuples: the 16-byte form
+                        log("compact tuples not usable (%r)" % (e,))
+                        compact = False
+                if n and not compact:
                     eng.hits_to(h_hits.data_ptr(), n, False)
                 t_dn = time.perf_counter()
                 times.append(((t_dn - t1) * 1e3, (t_up - t1) * 1e3, (t_m - t_up) * 1e3, (t_dn - t_m) * 1e3))
@@ -503,14 +516,18 @@ def main() -> int:
             best = min(times)
             legs["survey_scope"] = {
                 "ms_per_pass": best[0], "reads_per_s": wl.n_raw_reads / (best[0] / 1e3),
-                "ms_upload_and_pack": best[1], "ms_match_first_pass": best[2], "ms_tuples_to_host": best[3],
+                "ms_queue_upload": best[1], "ms_match_overlapping_upload": best[2], "ms_tuples_to_host": best[3],
                 "all_reps_ms": [round(x[0], 3) for x in times],
-                "bytes_up": int(h_packed.numel() + h_off.numel() * 8), "bytes_down": int(n0 * 16),
-                "what": "packed unique reads + offsets in pinned host memory -> musc_reads_load_packed -> "
-                        "musc_match_device (sizing pass) -> musc_hits_copy into pinned host memory; database + "
-                        "index resident (uploaded once, timed under one_off); best of 3",
+                "bytes_up": int(h_packed.numel()), "bytes_down": int(n0 * 4 + n_loaded) if compact else int(n0 * 16),
+                "tuple_form": "compact: u32 word %s + one count byte per read" % cbits if compact else "16-byte tuples",
+                "what": "SURVEY.md 8d's timer: packed unique reads (2 bits per base, fixed length: nothing else crosses "
+                        "PCIe) in pinned host memory -> musc_reads_load_packed32(async): upload queued in pieces on a copy "
+                        "stream -> musc_match_device (a sizing pass: the reads are new) packs and matches each batch as "
+                        "its pieces arrive -> tuples into pinned host memory; database + index resident (uploaded "
+                        "once, timed under one_off); best of 3",
             }
-            del h_packed, h_off
+            del h_words, h_counts
+            del h_packed
         # (3) a pass over freshly loaded reads with every buffer already allocated (what the CLI and
         # any service matching new batches pay per batch instead of the sized pass)
         if keep_reads and not args.unsorted:

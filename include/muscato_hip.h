@@ -168,6 +168,17 @@ int musc_reads_load_ascii(musc_ctx* ctx, const char* seqs, const uint64_t* offse
                           uint64_t nreads, int on_device);
 int musc_reads_load_packed(musc_ctx* ctx, const uint8_t* bases2bit, const uint8_t* nmask,
                            const uint64_t* read_offsets, uint64_t nreads);
+/* The same with 32-bit lengths instead of 64-bit offsets (`const uint32_t*
+ * lengths_or_offsets`): lengths[i] = bases of read i, or lengths == NULL: every read has fixed_len
+ * bases (nothing but the bases crosses PCIe then).  The reads sit back to back in the 2-bit stream.
+ * async != 0 (fixed length, no mask): the call returns once the upload is QUEUED -- in pieces, on a
+ * copy stream of its own -- and the next musc_match* on the context packs and matches each batch of
+ * reads as its piece arrives, so that upload and matching overlap (the reference's equivalent is
+ * muscato_screen reading reads_sorted.txt.sz while it hashes, cmd/muscato_screen/main.go:116-207).
+ * The caller's buffer must then stay valid until that musc_match* call (or musc_destroy) returns;
+ * pinned memory makes the upload asynchronous in fact. */
+int musc_reads_load_packed32(musc_ctx* ctx, const uint8_t* bases2bit, const uint8_t* nmask,
+                             const uint32_t* lengths, uint32_t fixed_len, uint64_t nreads, int async);
 
 /* Read prep on the GPU: replaces the bytewise sort of the prepared reads (sortReads in
  * cmd/muscato/main.go: GNU sort of the `seq\tname` lines under LC_ALL=C) and the collapse of

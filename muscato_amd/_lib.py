@@ -56,7 +56,7 @@ class MuscStats(ctypes.Structure):
 SYMBOLS = [
     "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error",
     "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for",
-    "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique",
+    "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_load_packed32", "musc_reads_sort_unique",
     "musc_match_device", "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_free_hits",
     "musc_get_stats", "musc_gather", "musc_gather_rccl", "musc_rccl_probe", "musc_overflow_probes", "musc_free_u32",
 ]
@@ -90,6 +90,7 @@ def load() -> ctypes.CDLL:
     lib.musc_db_build_index_for.argtypes = [vp, ctypes.POINTER(MuscParams), i32]
     lib.musc_reads_load_ascii.argtypes = [vp, vp, vp, u64, ctypes.c_int]
     lib.musc_reads_load_packed.argtypes = [vp, vp, vp, vp, u64]
+    lib.musc_reads_load_packed32.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, u64, ctypes.c_int]
     lib.musc_reads_sort_unique.argtypes = [vp, vp, vp, u64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                            ctypes.POINTER(u64)]
     lib.musc_match_device.argtypes = [vp, ctypes.POINTER(MuscParams), ctypes.POINTER(u64)]
@@ -110,7 +111,7 @@ def load() -> ctypes.CDLL:
     lib.musc_gather_rccl.argtypes = lib.musc_gather.argtypes
     lib.musc_rccl_probe.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
     for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for", "musc_db_build_index_for",
-                 "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_sort_unique", "musc_match_device",
+                 "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_load_packed32", "musc_reads_sort_unique", "musc_match_device",
                  "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_get_stats",
                  "musc_gather", "musc_gather_rccl", "musc_rccl_probe"):
         getattr(lib, name).restype = ctypes.c_int

@@ -261,6 +261,17 @@ class Engine:
                     "musc_reads_load_packed")
         self.n_reads = nreads
 
+    def load_reads_packed32_ptr(self, bases_ptr: int, mask_ptr: int, lengths_ptr: int, fixed_len: int, nreads: int,
+                                async_upload: bool = False) -> None:
+        """musc_reads_load_packed32: 2-bit bases back to back, optional 1-bit X mask (0 = none), uint32
+        lengths (0 = every read has fixed_len bases).  async_upload (fixed length, no mask): returns
+        once the upload is queued; the next match overlaps it batch by batch -- the host buffer must
+        stay valid until that match returns."""
+        self._check(self._lib.musc_reads_load_packed32(self._h, bases_ptr, mask_ptr or None, lengths_ptr or None,
+                                                       fixed_len, nreads, 1 if async_upload else 0),
+                    "musc_reads_load_packed32")
+        self.n_reads = nreads
+
     # ---- hot path
     def match_device(self, cfg: Config, apply_mmtol: bool = True, skip_block_check: bool = False,
                      n_shards: int = 1) -> int:

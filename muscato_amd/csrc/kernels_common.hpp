@@ -205,7 +205,7 @@ __global__ void k_pack_reads(const unsigned char* __restrict__ s, const uint32_t
       }
     }
     rd[t] = (len & 0xFFFFu) | (anyx ? READ_HAS_X : 0u);
-    rdm[t] = 0;
+    if (rdm) rdm[t] = 0;
     return;
   }
   uint32_t v = 0, mv = 0;
@@ -226,8 +226,41 @@ __global__ void k_pack_reads(const unsigned char* __restrict__ s, const uint32_t
     }
   }
   rd[t] = v;
-  rdm[t] = mv;
+  if (rdm) rdm[t] = mv;  // (no plane: the caller knows there is no X -- packed input without a mask)
   if (mv) atomicOr(has_x, 1u);
+}
+
+// reads of one length L, back to back in a 2-bit stream (no X): one thread per (read, record word);
+// reads [first, first + n) of the stream -> their records
+MUSC_KERNEL void k_pack_reads_fixed(const uint32_t* __restrict__ in2, uint64_t first, uint64_t n, uint32_t L, int rw,
+                                    uint32_t* __restrict__ rd) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * (uint64_t)rw) return;
+  const uint64_t r = first + t / (uint64_t)rw;
+  const uint32_t j = (uint32_t)(t % (uint64_t)rw);
+  uint32_t v = L;  // the length word
+  if (j + 1 < (uint32_t)rw) {
+    const uint32_t b0 = 16u * j;  // first base of this word within the read
+    v = 0;
+    if (b0 < L) {
+      const uint32_t nb = L - b0 < 16u ? L - b0 : 16u;
+      v = (uint32_t)ext64(in2, 2ull * (r * (uint64_t)L + b0)) & (nb == 16u ? 0xFFFFFFFFu : ((1u << (2u * nb)) - 1u));
+    }
+  }
+  rd[r * (uint64_t)rw + j] = v;
+}
+
+// u32 lengths -> u64 (the input of the offset scan)
+MUSC_KERNEL void k_widen_u32(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+  else if (i == n) out[i] = 0;
+}
+
+// offsets of reads of one length
+MUSC_KERNEL void k_iota_mul(uint64_t* __restrict__ out, uint64_t n, uint64_t step) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) out[i] = i * step;
 }
 
 // ------------------------------------------------------------------------------------

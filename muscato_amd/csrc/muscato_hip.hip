@@ -174,6 +174,20 @@ struct musc_ctx {
   int rw = 0;
   uint32_t max_len = 0;
 
+  // musc_reads_load_packed32(async): reads of one length on their way from the host -- the 2-bit
+  // stream goes to `stage` in pieces on the copy stream s_up, an event per piece; a pass packs the
+  // records of a batch (k_pack_reads_fixed) when the batch's pieces have arrived
+  struct Upload {
+    uint32_t* stage = nullptr;
+    uint64_t stage_words = 0;
+    hipStream_t s_up = nullptr;
+    std::vector<hipEvent_t> ev;
+    uint64_t piece = 0, n_pieces = 0;  // reads per piece, pieces of this upload
+    uint64_t packed_upto = 0;          // reads whose records exist
+    uint32_t L = 0;
+    bool active = false;               // records are still missing
+  } up;
+
   // per-batch work buffers
   // what k_screen hands to k_confirm, twice: in a pipelined pass k_screen fills one set on the
   // screen stream while k_confirm and k_compact drain the other on the confirm stream
@@ -359,6 +373,10 @@ void free_db(musc_ctx* c) {
 }
 
 void free_reads(musc_ctx* c) {
+  if (c->up.active) {  // an upload nobody matched: the caller's buffer is borrowed until it ends
+    (void)hipStreamSynchronize(c->up.s_up);
+    c->up.active = false;
+  }
   if (c->rd) (void)hipFree(c->rd);
   if (c->rdm) (void)hipFree(c->rdm);
   c->rd = c->rdm = nullptr;
@@ -553,6 +571,9 @@ void musc_destroy(musc_ctx* c) {
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  for (hipEvent_t ev : c->up.ev) (void)hipEventDestroy(ev);
+  if (c->up.stage) (void)hipFree(c->up.stage);
+  if (c->up.s_up) (void)hipStreamDestroy(c->up.s_up);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -972,6 +993,25 @@ int musc_db_build_index_for(musc_ctx* c, const musc_params* P, int32_t max_read_
 
 // ---------------------------------------------------------------- reads
 
+// The records of reads [r0, r0 + n) must exist before stream `st` goes on: for the pieces of an
+// asynchronous upload (reads_load_fixed) that are still missing, `st` waits for their arrival and
+// packs them.  A no-op once every record exists.
+static int upload_prepare(musc_ctx* c, uint64_t r0, uint64_t n, hipStream_t st) {
+  musc_ctx::Upload& u = c->up;
+  if (!u.active) return 0;
+  const uint64_t want = std::min<uint64_t>(r0 + n, c->nreads);
+  while (u.packed_upto < want) {
+    const uint64_t i = u.packed_upto / u.piece;
+    const uint64_t first = i * u.piece, cnt = std::min<uint64_t>(u.piece, c->nreads - first);
+    HIPCHK(c, hipStreamWaitEvent(st, u.ev[i], 0));
+    hipLaunchKernelGGL(k_pack_reads_fixed, dim3(nblk(cnt * (uint64_t)c->rw, 256)), dim3(256), 0, st, u.stage, first, cnt, u.L, c->rw, c->rd);
+    HIPCHK(c, hipGetLastError());
+    u.packed_upto = first + cnt;
+  }
+  if (u.packed_upto >= c->nreads) u.active = false;
+  return 0;
+}
+
 static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* bases2bit, const uint8_t* nmask,
                       const uint64_t* offsets, uint64_t nreads, int on_device, bool packed) {
   HIPCHK(c, hipSetDevice(c->device));
@@ -1009,9 +1049,13 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
   const uint64_t words = nreads * (uint64_t)rw;
   if (words >= (1ull << 32)) return fail(c, 2, "too many read words for one dispatch (reads x record words >= 2^32)");
   HIPCHK(c, hipMalloc((void**)&c->rd, words * 4 + 256));
-  HIPCHK(c, hipMalloc((void**)&c->rdm, words * 4 + 256));
   HIPCHK(c, hipMemsetAsync(c->rd + words, 0, 256, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->rdm + words, 0, 256, c->stream));
+  // the mask plane only where an X can turn up: ASCII input, or packed input that comes with a mask
+  const bool may_have_x = !packed || nmask != nullptr;
+  if (may_have_x) {
+    HIPCHK(c, hipMalloc((void**)&c->rdm, words * 4 + 256));
+    HIPCHK(c, hipMemsetAsync(c->rdm + words, 0, 256, c->stream));
+  }
   uint32_t* d_hasx = c->d_flag;
   HIPCHK(c, hipMemsetAsync(d_hasx, 0, 4, c->stream));
   unsigned char *t1 = nullptr, *t2 = nullptr;
@@ -1043,11 +1087,102 @@ static int reads_load(musc_ctx* c, const unsigned char* ascii, const uint8_t* ba
   HIPCHK(c, hipMemcpyAsync(&hasx, d_hasx, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->reads_have_x = hasx != 0;
-  if (!hasx) {
+  if (!hasx && c->rdm) {
     (void)hipFree(c->rdm);
     c->rdm = nullptr;
   }
   return 0;
+}
+
+// Reads of one length without X: the 2-bit stream is all that crosses PCIe.  async: the upload is
+// queued in pieces on a copy stream and the records are made batch by batch by the pass that needs
+// them (upload_prepare), so that upload and matching overlap.
+static int reads_load_fixed(musc_ctx* c, const uint8_t* bases2bit, uint32_t L, uint64_t nreads, int async) {
+  HIPCHK(c, hipSetDevice(c->device));
+  free_reads(c);
+  if (nreads >= 0xFFFFFFF0ull) return fail(c, 2, "too many reads for 32-bit read_idx");
+  if (L > 65535) return fail(c, 2, "read of %u bases exceeds the 65535-base record limit", L);
+  c->nreads = nreads;
+  if (nreads == 0) {
+    c->rw = 4;
+    return 0;
+  }
+  c->max_len = L;
+  int rw = (int)((2ull * L + 31) / 32) + 1;
+  rw = (rw + 3) & ~3;
+  if (rw < 4) rw = 4;
+  c->rw = rw;
+  const uint64_t words = nreads * (uint64_t)rw;
+  if (words >= (1ull << 32)) return fail(c, 2, "too many read words for one dispatch (reads x record words >= 2^32)");
+  HIPCHK(c, hipMalloc((void**)&c->rd, words * 4 + 256));
+  HIPCHK(c, hipMemsetAsync(c->rd + words, 0, 256, c->stream));
+  c->reads_have_x = false;
+  musc_ctx::Upload& u = c->up;
+  const uint64_t total_bytes = (nreads * (uint64_t)L + 3) / 4;
+  const uint64_t need_words = (total_bytes + 3) / 4 + 4;  // (k_pack_reads_fixed reads up to two words past a read's last)
+  if (u.stage_words < need_words) {
+    if (u.stage) (void)hipFree(u.stage);
+    u.stage = nullptr;
+    u.stage_words = 0;
+    HIPCHK(c, hipMalloc((void**)&u.stage, need_words * 4));
+    u.stage_words = need_words;
+  }
+  if (!u.s_up) HIPCHK(c, hipStreamCreateWithFlags(&u.s_up, hipStreamNonBlocking));
+  // pieces of whole bytes of the stream (4 | piece) and whole wave-tiles (64 | piece), a quarter of a
+  // pass's batch each: the first batch can start when a quarter of it has arrived... no: a batch
+  // needs all its pieces, but the NEXT batch's pieces arrive while this one is matched
+  uint64_t piece = std::max<uint64_t>(c->batch_reads / 4, 64);
+  piece = (piece + 63) & ~63ull;
+  u.piece = piece;
+  u.n_pieces = (nreads + piece - 1) / piece;
+  u.L = L;
+  u.packed_upto = 0;
+  while (u.ev.size() < u.n_pieces) {
+    hipEvent_t e = nullptr;
+    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    u.ev.push_back(e);
+  }
+  HIPCHK(c, hipMemsetAsync(u.stage + (need_words - 4), 0, 16, u.s_up));
+  for (uint64_t i = 0; i < u.n_pieces; i++) {
+    const uint64_t b0 = i * piece * (uint64_t)L / 4;  // (64 | piece: a whole number of bytes)
+    const uint64_t b1 = std::min<uint64_t>(((i + 1) * piece * (uint64_t)L + 3) / 4, total_bytes);
+    HIPCHK(c, hipMemcpyAsync(reinterpret_cast<uint8_t*>(u.stage) + b0, bases2bit + b0, b1 - b0, hipMemcpyHostToDevice, u.s_up));
+    HIPCHK(c, hipEventRecord(u.ev[i], u.s_up));
+  }
+  u.active = true;
+  if (!async) {
+    int rc = upload_prepare(c, 0, nreads, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+int musc_reads_load_packed32(musc_ctx* c, const uint8_t* bases2bit, const uint8_t* nmask, const uint32_t* lengths,
+                             uint32_t fixed_len, uint64_t nreads, int async) {
+  if (!c) return 1;
+  if (!bases2bit && nreads) return fail(c, 2, "musc_reads_load_packed32: NULL input");
+  if (!lengths && !nmask) return reads_load_fixed(c, bases2bit, fixed_len, nreads, async);
+  // lengths and / or a mask: offsets are made on the device (a scan of the lengths, or multiples of
+  // fixed_len) and the general loader takes over
+  HIPCHK(c, hipSetDevice(c->device));
+  TmpBufs B;
+  uint64_t *d_off = nullptr, *stmp = nullptr;
+  uint32_t* d_len = nullptr;
+  HIPCHK(c, B.alloc(&d_off, (nreads + 2) * 8));
+  if (lengths) {
+    HIPCHK(c, B.alloc(&d_len, (nreads + 1) * 4));
+    HIPCHK(c, B.alloc(&stmp, scan_tmp_elems(nreads + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(d_len, lengths, nreads * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_widen_u32, dim3(nblk(nreads + 1, 256)), dim3(256), 0, c->stream, d_len, nreads, d_off);
+    HIPCHK(c, hipGetLastError());
+    int rc = scan_u64(c, d_off, d_off, nreads + 1, stmp);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(k_iota_mul, dim3(nblk(nreads + 1, 256)), dim3(256), 0, c->stream, d_off, nreads, (uint64_t)fixed_len);
+    HIPCHK(c, hipGetLastError());
+  }
+  return reads_load(c, nullptr, bases2bit, nmask, d_off, nreads, 1, true);
 }
 
 int musc_reads_load_ascii(musc_ctx* c, const char* seqs, const uint64_t* offsets, uint64_t nreads, int on_device) {
@@ -1265,6 +1400,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       const bool more = r0 + n < c->nreads;
       const uint64_t next_grid = more ? std::min<uint64_t>(nblk((uint32_t)std::min<uint64_t>(bsz, c->nreads - r0 - n), TILE), resident) : 0;
       const bool defer = fuse && more && next_grid == sgrid;  // this batch's tuples wait for the next launch
+      if ((rc = upload_prepare(c, r0, n, c->stream))) return rc;  // (reads still on their way from the host)
       tm.begin(0);
       {
         Range rg("k_match");
@@ -1558,6 +1694,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       HIPCHK(c, hipMemsetAsync(c->counters + 8, 0, 8 * sizeof(unsigned long long), c->stream));
     }
 
+    if ((rc = upload_prepare(c, r0, n, c->stream))) return rc;  // (reads still on their way from the host)
     tm.begin(0);
     {
       Range rg("k_screen");

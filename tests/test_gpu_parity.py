@@ -114,6 +114,53 @@ def test_packed_loaders_equal_ascii_loaders(eng):
         assert_same(got, exp)
 
 
+def test_packed32_loader_lengths_fixed_and_streamed(eng, monkeypatch):
+    """musc_reads_load_packed32 (SURVEY.md 8b's `uint32 lengths_or_offsets` form): u32 lengths with
+    and without an X mask against the ASCII loader; reads of one length as the bare 2-bit stream,
+    loaded at once and as an asynchronous upload that the match overlaps batch by batch (many small
+    batches: every piece boundary is crossed) -- the same tuples every time, and again on the
+    repeat (sized) pass over the streamed reads."""
+    from muscato_amd import sorted_hits
+    from muscato_amd.api import concat, pack_2bit
+    for seed in (3, 7, 9, 10):  # seeds 3, 9 use the X alphabet
+        ocfg, reads, targets = make_case(seed)
+        exp = gpu_hits(eng, ocfg, reads, targets, False)
+        buf, off = concat(reads)
+        packed, mask = pack_2bit(buf, int(off[-1]))
+        packed = np.concatenate([packed, np.zeros(8, np.uint8)])
+        lens = np.diff(off.astype(np.int64)).astype(np.uint32)
+        eng.load_reads_packed32_ptr(packed.ctypes.data, mask.ctypes.data if mask is not None else 0, lens.ctypes.data, 0, len(reads))
+        assert_same(sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False)), exp)
+    # reads of one length, no X
+    rng = random.Random(77)
+    targets = [rand_seq(rng, 700, b"ACGT") for _ in range(60)]
+    rs = set()
+    while len(rs) < 3000:
+        t = rng.choice(targets)
+        p = rng.randint(0, len(t) - 90)
+        rs.add(mutate(rng, t[p:p + 90], 0.02, b"ACGT"))
+    reads = sorted(rs)
+    ocfg = orc.Config(Windows=[0, 22], WindowWidth=11, PMatch=0.95, MinDinuc=2, MaxReadLength=90, MaxMatches=100000, MMTol=1)
+    exp = gpu_hits(eng, ocfg, reads, targets, False)
+    buf, off = concat(reads)
+    packed, mask = pack_2bit(buf, int(off[-1]))
+    assert mask is None
+    packed = np.concatenate([packed, np.zeros(8, np.uint8)])
+    from muscato_amd import Engine
+    for batch in ("16777216", "320", "257"):
+        monkeypatch.setenv("MUSC_BATCH_READS", batch)  # read at musc_init
+        with Engine(0) as e2:
+            e2.load_targets(targets)
+            for asyn in (False, True):
+                e2.load_reads_packed32_ptr(packed.ctypes.data, 0, 0, 90, len(reads), async_upload=asyn)
+                for rep in range(2):
+                    assert_same(sorted_hits(e2.match(to_cfg(ocfg), apply_mmtol=False)), exp)
+            # an upload nobody matches is waited for when the reads are replaced
+            e2.load_reads_packed32_ptr(packed.ctypes.data, 0, 0, 90, len(reads), async_upload=True)
+            e2.load_reads(reads[:100])
+            assert len(e2.match(to_cfg(ocfg), apply_mmtol=False)) > 0
+
+
 def test_literal_100_rule_on_gpu(eng):
     rng = random.Random(5)
     t = rand_seq(rng, 300, b"ACGT")
