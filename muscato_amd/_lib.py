@@ -73,6 +73,18 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             "muscato_amd: %s is missing -- build it with `python -m muscato_amd.build` "
             "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    # torch ships a HIP runtime of its own; this library links the system one.  Both work in one
+    # process when torch's opens the device first, and torch reports "no ROCm-capable device" when it
+    # comes second.  A process that has torch loaded gets that order here, whatever the caller does
+    # next (the library itself never imports torch).
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for s in SYMBOLS:
         if not hasattr(lib, s):

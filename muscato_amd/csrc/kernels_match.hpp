@@ -374,7 +374,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   constexpr int WMAX = W2 ? 2 : CTX_MAX_W;
   constexpr int NWAVE = TILE / 64;
   extern __shared__ uint32_t s_dyn[];  // block_mode != 0: NWAVE x W x 64 per-(window, read) counters, then (mode 1) the sketch
-  __shared__ uint32_t s_img[NWAVE][WMAX * WT * 8];  // the read's image per (window, read)
+  __shared__ __attribute__((aligned(16))) uint32_t s_img[NWAVE][WMAX * WT * 8];  // the read's image per (window, read)
   __shared__ uint32_t s_meta[NWAVE][WT];            // length | budget << 17 | valid windows << 24
   __shared__ uint32_t s_bb[NWAVE][WMAX * WT];       // bucket of (window, read), WB_NONE when the window takes no part
   __shared__ uint32_t s_oc[NWAVE][WMAX * WT];       // phase B/C: overflow entries of the probe; phase D: cnt[64], base[64]

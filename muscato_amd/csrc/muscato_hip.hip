@@ -97,6 +97,33 @@ struct Range {
   }
 };
 
+// A stream capture in progress is ended on every exit path: an early return between
+// hipStreamBeginCapture and hipStreamEndCapture would leave the stream capturing, and every later
+// call on the context would fail until it is destroyed.
+struct CaptureGuard {
+  hipStream_t st = nullptr;
+  bool active = false;
+  hipError_t begin(hipStream_t s) {
+    const hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      st = s;
+      active = true;
+    }
+    return e;
+  }
+  hipError_t end(hipGraph_t* g) {
+    active = false;
+    return hipStreamEndCapture(st, g);
+  }
+  ~CaptureGuard() {
+    if (!active) return;
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(st, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+  }
+};
+
 // temporary device allocations of one call, released on every exit path
 struct TmpBufs {
   void* p[16] = {};
@@ -234,6 +261,7 @@ struct musc_ctx {
   // MUSC_GRAPH=1: the sized pass on context buckets as a hipGraph (one launch instead of seven per
   // batch; no per-kernel timing in that mode)
   hipGraphExec_t graph_exec = nullptr;
+  bool graph_failed = false;  // capture or instantiation failed once: sized passes run launch by launch
   uint64_t graph_epoch = 0;
   musc_params graph_params;
   int graph_block_mode = -1;
@@ -916,6 +944,8 @@ static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
     c->rdx_epoch = c->data_epoch;
     c->xok_epoch = ~0ull;
   }
+  // (the budget table covers the reads in hand whatever length the caller planned the index for)
+  max_len = std::max(max_len, c->max_len);
   if (c->xok_epoch == c->data_epoch && c->xok_pmatch == P->pmatch && c->xok_mmp1 == P->max_mismatch_p1) return c->xok;
   std::vector<uint16_t> tab((size_t)max_len + 2);
   for (uint32_t L = 0; L < tab.size(); L++) {  // the budget exactly as musc_match_device builds it
@@ -1338,7 +1368,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
   // launch per pass.  Every buffer of a sized pass is fixed, so the captured arguments stay valid;
   // any pass that sizes drops the graph.
   const char* genv = getenv("MUSC_GRAPH");
-  const bool use_graph = sized && genv && atoi(genv) > 0;
+  const bool use_graph = sized && genv && atoi(genv) > 0 && !c->graph_failed;
   if (!sized && c->graph_exec) {
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
@@ -1363,9 +1393,17 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       c->graph_exec = nullptr;
     }
     tm.off = capture || replay;
+    CaptureGuard cap;  // (ends the capture if this attempt leaves early)
     if (!replay) {
-      if (capture) HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      else HIPCHK(c, hipEventRecord(ev0, c->stream));
+      if (capture) {
+        if (cap.begin(c->stream) != hipSuccess) {  // no capture on this stream: the plain sized pass
+          (void)hipGetLastError();
+          c->graph_failed = true;
+          return musc_match_device(c, P, nhits);
+        }
+      } else {
+        HIPCHK(c, hipEventRecord(ev0, c->stream));
+      }
     }
     uint64_t n_cand = 0, n_cmp = 0, n_windows = 0, n_ovf = 0, r0 = 0;
     c->stats.n_batches = 0;
@@ -1479,12 +1517,14 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     }
     if (capture) {
       hipGraph_t g = nullptr;
-      HIPCHK(c, hipStreamEndCapture(c->stream, &g));
-      const hipError_t ge = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(g);
-      if (ge != hipSuccess) {
+      hipError_t ge = cap.end(&g);
+      if (ge == hipSuccess) ge = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+      if (g) (void)hipGraphDestroy(g);
+      if (ge != hipSuccess) {  // the graph is an optimisation: without it the pass runs launch by launch
+        (void)hipGetLastError();
         c->graph_exec = nullptr;
-        return fail(c, 10, "hipGraphInstantiate failed: %s", hipGetErrorString(ge));
+        c->graph_failed = true;
+        return musc_match_device(c, P, nhits);
       }
       c->graph_epoch = c->data_epoch;
       c->graph_params = *P;

@@ -58,16 +58,17 @@ class HitGatherer:
     `isend`s its buffer to rank `dst`, `dst` posts one `irecv` per peer into that peer's slab of a
     rank-major receive buffer, all of them inside one ncclGroupStart/End (torch's
     batch_isend_irecv), so the seven incoming transfers of an 8-GPU node run side by side on the
-    seven xGMI links of `dst` instead of one after the other.  No host round trip: the tuple count
-    rides in the last row of the buffer.  The transfer of pass i runs on the communicator's stream
-    while pass i+1 is being matched.
+    seven xGMI links of `dst` instead of one after the other.  Only the rows in use travel: the
+    ranks agree on every rank's row count with one small all_gather per pass (the host knows its own
+    count when the match returns), so link load follows the tuples, not the capacity.  The transfer
+    of pass i runs on the communicator's stream while pass i+1 is being matched.
 
-    Every rank owns `depth` send buffers of `cap` + 1 rows; row `cap` carries the tuple count.  With
+    Every rank owns `depth` send buffers of 1 + `cap` rows; row 0 carries the tuple count.  With
     `packed=True` a row is one int64 word (the layout of musc_hits_copy_packed: half the bytes on
     the links; fill() must then write words that already include the shard's read base),
     otherwise four int32 (read, gene, pos, nmiss).  Rank `dst` owns `depth` receive buffers of
-    world x (cap + 1) rows.  submit() fills the next send buffer through `fill(buf_rows) -> n`
-    (e.g. Engine.hits_to), rebases column 0 by `read_base` and starts the transfers; it first
+    world x (1 + cap) rows.  submit() fills the next send buffer through `fill(rows) -> n` (`rows` =
+    the buffer behind its header row; e.g. Engine.hits_to), rebases column 0 by `read_base` and starts the transfers; it first
     waits for the ones issued `depth` passes earlier, whose buffers it reuses.  finish() waits for
     everything; on `dst`, counts(k) / last_result() then give the tuples per rank -- rank-order
     concatenation is the global read order."""
@@ -84,7 +85,7 @@ class HitGatherer:
         self.cw = (self.compact_reads + 3) // 4  # words of the count bytes
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        shape, dtype = ((self.cap + 1,), torch.int64) if packed else ((self.cap + 1, 4), torch.int32)
+        shape, dtype = ((1 + self.cap,), torch.int64) if packed else ((1 + self.cap, 4), torch.int32)
         if self.compact_reads:
             shape, dtype = (2 + self.cw + self.cap,), torch.int32
         self.recv = None
@@ -124,7 +125,7 @@ class HitGatherer:
         k = self.i % self.depth
         self._wait(k)
         buf = self.send[k]
-        n = fill(buf)
+        n = fill(buf if self.compact_reads else buf[1:])
         nreads = 0
         if self.compact_reads:
             n, nreads = n
@@ -134,6 +135,7 @@ class HitGatherer:
         if n > self.cap:
             raise RuntimeError("HitGatherer: %d hits exceed the agreed capacity %d" % (n, self.cap))
         if self.compact_reads:
+            rows = 2 + self.cw + n  # header words, count bytes, one word per tuple
             if self.head is not None:
                 h = self.head[k]  # (free again: the transfers of `depth` passes ago were waited for)
                 h[0] = n
@@ -143,19 +145,29 @@ class HitGatherer:
                 buf[0] = n
                 buf[1] = int(nreads)
         elif self.packed:
+            rows = 1 + n
             if self.head is not None:
                 self.head[k][0] = n
-                buf[self.cap:].copy_(self.head[k][:1], non_blocking=True)
+                buf[:1].copy_(self.head[k][:1], non_blocking=True)
             else:
-                buf[self.cap] = n
+                buf[0] = n
         else:
+            rows = 1 + n
             if read_base and n:
-                buf[:n, 0] += read_base
-            buf[self.cap, 0] = n
-        if self.rank == self.dst:
-            ops = [dist.P2POp(dist.irecv, self.recv[k][r], r, self.group) for r in range(self.world) if r != self.dst]
+                buf[1:1 + n, 0] += read_base
+            buf[0, 0] = n
+        # every rank's row count, on every rank: the transfers carry the rows in use and nothing else
+        mine = torch.tensor([rows], dtype=torch.int64, device=buf.device)
+        allr = [torch.zeros(1, dtype=torch.int64, device=buf.device) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(allr, mine, group=self.group)
+            sizes = [int(t.item()) for t in allr]
         else:
-            ops = [dist.P2POp(dist.isend, buf, self.dst, self.group)]
+            sizes = [rows]
+        if self.rank == self.dst:
+            ops = [dist.P2POp(dist.irecv, self.recv[k][r][:sizes[r]], r, self.group) for r in range(self.world) if r != self.dst]
+        else:
+            ops = [dist.P2POp(dist.isend, buf[:rows], self.dst, self.group)]
         self.work[k] = dist.batch_isend_irecv(ops) if ops else []
         self.i += 1
         return n
@@ -165,7 +177,7 @@ class HitGatherer:
         if self.compact_reads:
             last = self.recv[k][:, 0]
         else:
-            last = self.recv[k][:, self.cap] if self.packed else self.recv[k][:, self.cap, 0]
+            last = self.recv[k][:, 0] if self.packed else self.recv[k][:, 0, 0]
         return [int(c) for c in last.tolist()]
 
     def compact_views(self, buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -212,7 +224,7 @@ class HitGatherer:
         k = (self.i - 1) % self.depth
         if self.compact_reads:
             raise RuntimeError("compact buffers carry no read numbers: use last_slabs() + unpack_compact()")
-        return torch.cat([self.recv[k][r][:c] for r, c in enumerate(self.counts(k))], dim=0)
+        return torch.cat([self.recv[k][r][1:1 + c] for r, c in enumerate(self.counts(k))], dim=0)
 
     def last_slabs(self) -> Optional[torch.Tensor]:
         """After finish(): rank dst's receive buffer of the last pass, one slab per rank."""

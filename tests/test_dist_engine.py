@@ -87,9 +87,11 @@ def _worker(rank, world, port, seed, outdir, use_gpu, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     on_dev = backend == "nccl"  # RCCL moves device buffers: the library fills them in place
+    # one GPU per rank where the box has them (RCCL refuses two ranks on one device); else device 0
+    gpu = rank if (on_dev and world > 1) else 0
     if on_dev:
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        torch.cuda.set_device(gpu)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from cases import make_case
@@ -102,13 +104,13 @@ def _worker(rank, world, port, seed, outdir, use_gpu, backend="gloo"):
     lo, hi = shard_range(len(reads), rank, world)
     if use_gpu:
         from muscato_amd import Engine
-        eng = Engine(0)
+        eng = Engine(gpu)
         eng.load_targets(targets)
     else:
         eng = OracleEngine(ocfg, targets)
     eng.load_reads(reads[lo:hi])
     n0 = eng.match_device(cfg, apply_mmtol=True, n_shards=world)
-    dev = torch.device("cuda", 0) if on_dev else torch.device("cpu")
+    dev = torch.device("cuda", gpu) if on_dev else torch.device("cpu")
     out = {}
     for packed in (False, True):
         g = HitGatherer(HitGatherer.agree_capacity(n0, dev), dev, depth=2, packed=packed)
@@ -227,3 +229,53 @@ def test_in_process_gather_entry_points():
         e.load_reads(reads)
         exp = sorted_hits(e.match(cfg, apply_mmtol=True))
     assert (sorted_hits(whole) == exp).all()
+
+
+def _n_gpus():
+    try:
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: HitGatherer over RCCL with a peer")
+@pytest.mark.parametrize("seed", [3, 14])
+def test_two_rank_rccl_gather_on_two_gpus(tmp_path, seed):
+    """The first thing to run on a multi-GPU box: two ranks, one GPU each, backend "nccl" -- the grouped
+    send / recv of HitGatherer with a real peer over xGMI, device buffers filled in place by the
+    library, in the 16-byte, packed and compact forms, against the single-process list.  (Skipped
+    on the one-GPU test boxes; the same code runs there over gloo and as a one-member RCCL group.)"""
+    _check(tmp_path, seed, use_gpu=True, world=2, backend="nccl")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: musc_gather_rccl with two contexts on two devices")
+def test_in_process_rccl_gather_on_two_gpus():
+    """musc_gather_rccl with n > 1 (ncclCommInitAll over two devices, grouped ncclSend / ncclRecv to the
+    first context's GPU, rebase there, one copy out) against musc_gather on the same contexts."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cases import make_case
+    from muscato_amd import Config, Engine, gather, sorted_hits
+    ocfg, reads, targets = make_case(14)
+    cfg = Config(Windows=list(ocfg.Windows), WindowWidth=ocfg.WindowWidth, PMatch=ocfg.PMatch, MinDinuc=ocfg.MinDinuc,
+                 MaxReadLength=ocfg.MaxReadLength, MaxMatches=ocfg.MaxMatches, MMTol=ocfg.MMTol, MatchMode=ocfg.MatchMode)
+    half = len(reads) // 2
+    with Engine(0) as a, Engine(1) as b:
+        for e, part in ((a, reads[:half]), (b, reads[half:])):
+            e.load_targets(targets)
+            e.load_reads(part)
+            e.match_device(cfg, apply_mmtol=True, n_shards=2)
+        via_host = gather([a, b], [0, half], rccl=False)
+        lib = a._lib
+        import ctypes
+        arr = (ctypes.c_void_p * 2)(a._h, b._h)
+        bases = (ctypes.c_uint64 * 2)(0, half)
+        ph, cnt = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = lib.musc_gather_rccl(arr, 2, bases, ctypes.byref(ph), ctypes.byref(cnt))
+        assert rc == 0, lib.musc_last_error(a._h).decode()
+        via_rccl = np.zeros((cnt.value, 4), dtype=np.uint32)
+        if cnt.value:
+            ctypes.memmove(via_rccl.ctypes.data, ph, cnt.value * 16)
+        lib.musc_free_hits(ph)
+    assert via_rccl.shape == via_host.shape and (via_rccl == via_host).all()
