@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # same guide: 6.29 TB/s measured float4 copy
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 def measured_traffic(workload_key, kernel):
@@ -545,6 +545,7 @@ def main() -> int:
     legs["cold_pass_device_ms"] = cold_device_ms
 
     rc = 0
+    tkey = args.workload + ("_classic" if args.index == "classic" else "")  # the workload's entry in TRAFFIC_FILE
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         total_raw = wl.total_raw_reads if strong else wl.n_raw_reads * world
@@ -561,7 +562,7 @@ def main() -> int:
         confirm_roof = {
             "kernel": "k_confirm", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-            "traffic": measured_traffic(args.workload, "k_confirm") if not args.reads else None,
+            "traffic": measured_traffic(tkey, "k_confirm") if not args.reads else None,
             "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc passes of this command, recorded; not measured by this run)",
             "algorithmic_bytes": "%d B per descriptor loaded (12 descriptor + %d read + %d target span) + 16 B per tuple written"
                                  % (12 + 2 * rec_b + 1, rec_b, rec_b + 1),
@@ -581,7 +582,7 @@ def main() -> int:
         screen_roof = {
             "kernel": "k_screen", "bound": "hbm", "achieved": scr_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": scr_ach / HBM_PEAK_GBS, "frac_of_measured_copy_peak": scr_ach / HBM_COPY_GBS,
-            "traffic": measured_traffic(args.workload, "k_screen") if not args.reads else None,
+            "traffic": measured_traffic(tkey, "k_screen") if not args.reads else None,
             "traffic_source": TRAFFIC_FILE + " (recorded PMC passes; not measured by this run)",
             "algorithmic_bytes": "%d B per read record + 8 B bucket header per probe + 16 B per index entry walked + "
                                  "12 B per descriptor written" % rec_b,
@@ -612,7 +613,7 @@ def main() -> int:
                 "kernel": kname + " (screen + confirm + per-read selection, context buckets)", "bound": "hbm",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
-                "traffic": measured_traffic(args.workload, kname) if not args.reads else None,
+                "traffic": measured_traffic(tkey, kname) if not args.reads else None,
                 "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc passes of this command, recorded; not measured by this run)",
                 "algorithmic_bytes": "%d B per read record + 128 B bucket line per probe + 40 B per overflow entry walked + "
                                      "16 B per tuple staged" % rec_b,

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of the hot kernels from the separate rocprofv3 --pmc passes of collect.sh.
+"""HBM bytes per launch of the hot kernels from separate rocprofv3 --pmc passes (collect.sh).
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 a 128-byte read request is tallied as 64 bytes,
 so FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section) and cross-checked against
 TCC_EA0_RDREQ_128B x 128 B + the 32/64-byte requests.  Infinity-Cache hits are counted by these
 memory-side counters, so "traffic" is what left the L2s, an upper bound on what reached HBM.
-usage: traffic_from_pmc.py <prof dir> <workload key> <kernel prefix>...
+usage: traffic_from_pmc.py <prof dir> <workload key> <kernel prefix>...   -> JSON {key: {kernel: ...}}
 """
 import csv
 import glob
@@ -41,11 +41,7 @@ def main(root, key, prefixes):
             "tcc_hit": mean.get("TCC_HIT_sum"), "tcc_miss": mean.get("TCC_MISS_sum"),
             "traffic_bytes_per_launch": fetch + write,
         }
-    print(json.dumps({key: out, "method": (
-        "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --workload cfg3 --steps 1 "
-        "--warmup 1 [--index classic]` (profiles/collect.sh), mean over the kernel's dispatches; FETCH_SIZE doubled as "
-        "MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B), cross-checked against the "
-        "TCC_EA0_RDREQ counters by request size; memory-side counters include Infinity-Cache hits")}, indent=1))
+    print(json.dumps({key: out}, indent=1))
 
 
 if __name__ == "__main__":

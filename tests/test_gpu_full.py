@@ -199,6 +199,9 @@ def test_baseline_config_at_full_size(name, index, monkeypatch):
     exp, _, _ = literal.match_arrays(rbuf, rso, gbuf, gso,
                                      literal.make_params(OC, bloom_size=400_000_000, num_hash=20, nthreads=16))
     _log("%s: literal oracle on %d reads x %d targets: %d tuples in %.1fs" % (name, ns, nt, len(exp), time.time() - t0))
+    # a sanity bound on the SAMPLE's usefulness, not on parity: it must hold enough tuples to mean
+    # something.  0.1 per sampled read: cfg3's sample has ~0.8 tuples per read, the cfg5 shard's ~0.19
+    # (the sample's targets are 1 % of the shard's 10 M sequences, so most planted reads lose theirs)
     assert len(exp) > 0.1 * ns
     with Engine(0) as e2:
         e2.load_targets_arrays(gbuf, gso)
