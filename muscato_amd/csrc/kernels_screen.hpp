@@ -209,12 +209,18 @@ DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values der
 #ifndef SCR_ROUNDS
 #define SCR_ROUNDS 4  // quad rounds whose bucket loads are in flight together (8 per chunk)
 #endif
+#ifndef SCR_LROUNDS
+#define SCR_LROUNDS 8  // line buckets: rounds of eight lines whose loads are in flight together (16 per chunk)
+#endif
 #ifndef SCR_WAVES
 #define SCR_WAVES 4  // waves per SIMD the register allocator has to leave room for
 #endif
 // ONE: at most two windows, i.e. a single chunk -- the compiler then keeps nothing alive across
 // chunks (59 instead of 80 VGPRs without mask planes) and eight waves fit a SIMD.
-template <int RW, bool MASK, bool ONE>
+// LINES: the index is a table of LineBucket (kernels_index.hpp): a probe's line -- header + seven
+// entries -- is fetched by EIGHT lanes (16 bytes each, a wave instruction brings eight whole lines),
+// and the overflow entries of a bucket are a 128-byte-aligned run.
+template <int RW, bool MASK, bool ONE, bool LINES>
 __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen(const uint32_t* __restrict__ rd,
                                                  const uint32_t* __restrict__ rdm, uint64_t r0,
                                                  uint32_t n, int rw_rt, const PathParams* __restrict__ ppp,
@@ -355,6 +361,46 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
         s_bb[2 * tida + j] = b;
       }
       lds_barrier();
+      if constexpr (LINES) {
+        // ---- phase B (line buckets): eight lanes per probe; the lane that holds one of the line's seven
+        // entries tests it on the spot.  (No two-window descriptors here: each window's survivors are
+        // compared on their own; k_confirm's first-window rule keeps the tuple set the same.)
+        const uint4* __restrict__ TL = reinterpret_cast<const uint4*>(T);
+#pragma unroll 1
+        for (int h = 0; h < ((pp.dbg & 256) ? 0 : 16 / SCR_LROUNDS); h++) {
+          const uint32_t tidb = opaque(threadIdx.x);
+          const uint32_t lane = tidb & 63, wid = tidb >> 6, part = lane & 7;
+          uint4 v[SCR_LROUNDS];
+#pragma unroll
+          for (int rr = 0; rr < SCR_LROUNDS; rr++) {
+            const uint32_t b = s_bb[wid * 128 + (SCR_LROUNDS * h + rr) * 8 + (lane >> 3)];
+            v[rr] = make_uint4(0, 0, 0, 0);
+            if (b != WB_NONE && !(pp.dbg & 2)) {
+              const u32x4_v t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(TL + (uint64_t)b * 8u) + part);
+              v[rr] = make_uint4(t.x, t.y, t.z, t.w);
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < SCR_LROUNDS; rr++) {
+            const uint32_t probe = wid * 128 + (SCR_LROUNDS * h + rr) * 8 + (lane >> 3);
+            // the header sits in the first of the eight lanes: quad_perm [0,0,0,0], then the upper quad
+            // takes the lower quad's copy (row_shr:4)
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v[rr].x, 0x00, 0xF, 0xF, true);
+            const uint32_t c1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c0, 0x114, 0xF, 0xF, false);
+            const uint32_t cnt = part < 4 ? c0 : c1;
+            if (part == 0) {
+              ncand += cnt;
+              s_oc[probe] = cnt > LINE_INLINE ? cnt - LINE_INLINE : 0u;
+              s_ovf[probe] = (uint64_t)v[rr].y * 8u;  // the bucket's overflow run, in entries
+            }
+            const int k = k0 + (int)(probe & 1u), q1 = (probe & 1u) ? q1b : q1a;
+            uint32_t z = 0;
+            bool ok = part >= 1 && part - 1 < cnt && !(pp.dbg & 1);
+            if (ok) ok = screen_entry_ok(v[rr], q1, pp.ww, s_rfl[probe], s_lenbud[probe], &z);
+            append(ok, v[rr], probe, k, q1, z, false);
+          }
+        }
+      } else {
       // ---- phase B: buckets by quads; a wave fetches the 128 probes of its own 64 reads
 #pragma unroll 1
       for (int h = 0; h < ((pp.dbg & 256) ? 0 : 8 / SCR_ROUNDS); h++) {
@@ -413,6 +459,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
           ntwo += two;
           append(ok, v[rr], probe, k, q1, z, two);
         }
+      }
       }
       lds_barrier();
       // ---- phase C: the chunk's overflow entries as one flat list, in (read, window, entry) order

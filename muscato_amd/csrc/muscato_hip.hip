@@ -174,10 +174,11 @@ struct musc_ctx {
   // index
   int idx_ww = 0, idx_bits = 0, idx_direct = 0;
   int wide = 0;  // database >= 2^32 bases: 40-bit positions, gene numbers < 2^24
-  Bucket* idx_T = nullptr;  // 2^idx_bits buckets
+  Bucket* idx_T = nullptr;  // 2^idx_bits buckets: 64-byte Bucket, or (idx_lines) 128-byte LineBucket
   uint4* idx_E = nullptr;   // overflow entries
-  uint64_t idx_T_cap = 0, idx_E_cap = 0;  // allocated buckets / entries (kept across rebuilds:
-                                          // hipMalloc / hipFree of tens of GiB take seconds)
+  bool idx_lines = false;   // the table holds line buckets (kernels_index.hpp)
+  uint64_t idx_T_bytes = 0, idx_E_cap = 0;  // allocated table bytes / entries (kept across rebuilds:
+                                            // hipMalloc / hipFree of tens of GiB take seconds)
   uint64_t idx_n = 0;       // indexed window starts
   uint64_t idx_novf = 0;
   // index kind 1: context buckets (kernels_match.hpp); only one kind is resident at a time
@@ -477,7 +478,9 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
   if (stage == 0) {
     const dim3 sgrid(std::min(nblk(n, TILE), MAX_GRID));
 #define MUSC_LAUNCH_SCREEN(M, O)                                                                                  \
-    hipLaunchKernelGGL((k_screen<RW, M, O>), sgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, c->d_pp,     \
+    do { if (c->idx_lines) MUSC_LAUNCH_SCREEN2(M, O, true); else MUSC_LAUNCH_SCREEN2(M, O, false); } while (0)
+#define MUSC_LAUNCH_SCREEN2(M, O, LN)                                                                             \
+    hipLaunchKernelGGL((k_screen<RW, M, O, LN>), sgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, c->d_pp, \
                        c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,        \
                        c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, \
                        c->counters + 8)
@@ -485,6 +488,7 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
     if (c->rdm) { if (one) MUSC_LAUNCH_SCREEN(true, true); else MUSC_LAUNCH_SCREEN(true, false); }
     else { if (one) MUSC_LAUNCH_SCREEN(false, true); else MUSC_LAUNCH_SCREEN(false, false); }
 #undef MUSC_LAUNCH_SCREEN
+#undef MUSC_LAUNCH_SCREEN2
   } else {
     // persistent over tiles; the MaxMatches screening threshold assumes at most MAX_GRID workgroups
     const dim3 grid(std::min(nblk(n, TILE), MAX_GRID));
@@ -712,22 +716,110 @@ int musc_db_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t* nm
   return db_finish(c);
 }
 
+extern "C++" {
+// Which bucket layout the two-kernel index uses for this database and window width: line buckets
+// (LineBucket: a 128-byte line of seven entries + aligned overflow runs) when the direct table has
+// four or more window starts per key on average and the table fits, 64-byte buckets otherwise.
+// MUSC_INDEX=lines / classic64 force one or the other.
+static bool want_line_buckets(musc_ctx* c, int32_t ww, int bits, int direct) {
+  if (const char* e = getenv("MUSC_INDEX")) {
+    if (!strcmp(e, "lines")) return true;
+    if (!strcmp(e, "classic64")) return false;
+  }
+  if (!direct) return false;
+  (void)ww;
+  const uint64_t nb = 1ull << bits;
+  if (c->nbases < 4 * nb) return false;
+  size_t mfree = 0, mtotal = 0;
+  if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) return false;
+  const uint64_t have = (uint64_t)mfree + c->idx_T_bytes + c->idx_E_cap * sizeof(uint4) +
+                        (c->ctx_T ? c->ctx_T_cap * sizeof(CtxBucket) : 0) + (c->ctx_E ? c->ctx_E_cap * sizeof(CtxEntry) : 0);
+  // the table, the entries beyond the seventh in runs of eight (assume every bucket wastes half a run),
+  // 8 B per bucket of build temporaries, and room for the pass's buffers
+  const uint64_t need = (nb + 1) * (sizeof(LineBucket) + 8) + (c->nbases > 7 * nb ? (c->nbases - 7 * nb) * 16 : 0) + nb * 64 + (12ull << 30);
+  return need <= have;
+}
+
+template <class BT>
+static int build_index_buckets(musc_ctx* c, int32_t ww, int bits, int direct) {
+  const uint64_t nb = 1ull << bits;
+  c->ev_used = 0;
+  hipEvent_t e0 = pool_event(c), e1 = pool_event(c), e2 = pool_event(c), e3 = pool_event(c);
+  if (!e0 || !e1 || !e2 || !e3) return fail(c, 10, "hipEventCreate failed");
+  if (c->idx_T_bytes < (nb + 1) * sizeof(BT)) {
+    if (c->idx_T) (void)hipFree(c->idx_T);
+    c->idx_T = nullptr;
+    c->idx_T_bytes = 0;
+    HIPCHK(c, hipMalloc((void**)&c->idx_T, (nb + 1) * sizeof(BT)));
+    c->idx_T_bytes = (nb + 1) * sizeof(BT);
+  }
+  BT* const T = reinterpret_cast<BT*>(c->idx_T);
+  TmpBufs B;
+  uint64_t *tmp = nullptr, *stmp = nullptr;
+  HIPCHK(c, B.alloc(&tmp, (nb + 1 + 16) * 8));
+  HIPCHK(c, B.alloc(&stmp, scan_tmp_elems(nb + 1) * 8));
+  // timed: the device work (allocation above and below is host time, seconds for a 64 GiB table
+  // the first time, and not repeated)
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  HIPCHK(c, hipMemsetAsync(T, 0, (nb + 1) * sizeof(BT), c->stream));
+  const unsigned blocks = (unsigned)std::min<uint64_t>((c->nbases + 255) / 256, 1u << 22);
+  if (c->nbases) {
+    hipLaunchKernelGGL((k_index<false, BT>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
+                       c->nbases, ww, bits, direct, c->wide, T, (uint4*)nullptr);
+    HIPCHK(c, hipGetLastError());
+  }
+  // overflow lists: sizes -> offsets (u64: a 10 Gbp database has billions of overflow entries)
+  hipLaunchKernelGGL((k_index_ovf_count<BT>), dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, T, nb, tmp);
+  HIPCHK(c, hipGetLastError());
+  int rc = scan_u64(c, tmp, tmp, nb + 1, stmp);
+  if (rc) return rc;
+  uint64_t novf = 0;  // entries (64-byte buckets) or lines of eight entries (line buckets)
+  HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 8, hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL((k_index_ovf_set<BT>), dim3(nblk(nb, 256)), dim3(256), 0, c->stream, T, nb, tmp);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(e2, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  B.release();  // 8 bytes per bucket: returned before the overflow array is allocated
+  if (std::is_same<BT, LineBucket>::value) {
+    if (novf >= 0xFFFFFFF0ull) return fail(c, 5, "internal: %llu overflow lines do not fit 32-bit numbers", (unsigned long long)novf);
+    novf *= 8;
+  }
+  c->idx_novf = novf;
+  if (c->idx_E_cap < novf + 16) {
+    if (c->idx_E) (void)hipFree(c->idx_E);
+    c->idx_E = nullptr;
+    c->idx_E_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->idx_E, ((uint64_t)novf + 16) * sizeof(uint4)));
+    c->idx_E_cap = novf + 16;
+  }
+  HIPCHK(c, hipEventRecord(e3, c->stream));
+  if (c->nbases) {
+    hipLaunchKernelGGL((k_index<true, BT>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
+                       c->nbases, ww, bits, direct, c->wide, T, c->idx_E);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0, ms2 = 0;
+  (void)hipEventElapsedTime(&ms, e0, e2);
+  (void)hipEventElapsedTime(&ms2, e3, e1);
+  c->stats.ms_index_build = ms + ms2;
+  return 0;
+}
+}  // extern "C++"
+
 int musc_db_build_index(musc_ctx* c, int32_t ww) {
   if (!c) return 1;
   if (!c->db2) return fail(c, 4, "no database loaded");
   if (ww < 1 || ww > 4096) return fail(c, 2, "bad window width %d", ww);
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->idx_ww == ww && c->idx_kind == 0 && c->idx_T) return 0;
-  free_index(c);
-  drop_ctx_index(c);  // one index kind is resident at a time
-  c->idx_kind = 0;
   c->wide = c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE") != nullptr;
   if (c->wide && c->nseq >= (1u << 24))
     return fail(c, 5, "a database of 2^32 bases or more may hold at most 2^24 targets (has %u)", c->nseq);
   // Direct addressing (bucket = the 2*ww-bit key itself: exact, and bytewise-sorted reads walk
   // the table front to back) when that table is at most 32x the database and at most 2^30
-  // buckets (64 GiB); otherwise a hashed table with about one bucket per base, at most 2^31
-  // buckets (128 GiB; longer lists go to the overflow array).
+  // buckets (64 GiB; line buckets: 128 GiB); otherwise a hashed table with about one bucket per base, at
+  // most 2^31 buckets (128 GiB; longer lists go to the overflow array).
   int bits, direct = 0;
   const uint64_t floor_bases = std::max<uint64_t>(c->nbases, 1ull << 19);
   if (2 * ww <= 30 && (1ull << (2 * ww)) <= 32 * floor_bases) {
@@ -741,63 +833,14 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
     const int v = atoi(ov);
     if (v >= 8 && v <= 31) { bits = v; direct = 0; }
   }
-  const uint64_t nb = 1ull << bits;
-  c->ev_used = 0;
-  hipEvent_t e0 = pool_event(c), e1 = pool_event(c), e2 = pool_event(c), e3 = pool_event(c);
-  if (!e0 || !e1 || !e2 || !e3) return fail(c, 10, "hipEventCreate failed");
-  if (c->idx_T_cap < nb + 1) {
-    if (c->idx_T) (void)hipFree(c->idx_T);
-    c->idx_T = nullptr;
-    c->idx_T_cap = 0;
-    HIPCHK(c, hipMalloc((void**)&c->idx_T, (nb + 1) * sizeof(Bucket)));
-    c->idx_T_cap = nb + 1;
-  }
-  TmpBufs B;
-  uint64_t *tmp = nullptr, *stmp = nullptr;
-  HIPCHK(c, B.alloc(&tmp, (nb + 1 + 16) * 8));
-  HIPCHK(c, B.alloc(&stmp, scan_tmp_elems(nb + 1) * 8));
-  // timed: the device work (allocation above and below is host time, seconds for a 64 GiB table
-  // the first time, and not repeated)
-  HIPCHK(c, hipEventRecord(e0, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->idx_T, 0, (nb + 1) * sizeof(Bucket), c->stream));
-  const unsigned blocks = (unsigned)std::min<uint64_t>((c->nbases + 255) / 256, 1u << 22);
-  if (c->nbases) {
-    hipLaunchKernelGGL(k_index<false>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
-                       c->nbases, ww, bits, direct, c->wide, c->idx_T, (uint4*)nullptr);
-    HIPCHK(c, hipGetLastError());
-  }
-  // overflow lists: sizes -> offsets (u64: a 10 Gbp database has billions of overflow entries)
-  hipLaunchKernelGGL(k_index_ovf_count, dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
-  HIPCHK(c, hipGetLastError());
-  int rc = scan_u64(c, tmp, tmp, nb + 1, stmp);
+  const bool lines = want_line_buckets(c, ww, bits, direct) && bits <= 30;
+  if (c->idx_ww == ww && c->idx_kind == 0 && c->idx_T && c->idx_lines == lines) return 0;
+  free_index(c);
+  drop_ctx_index(c);  // one index kind is resident at a time
+  c->idx_kind = 0;
+  c->idx_lines = lines;
+  const int rc = lines ? build_index_buckets<LineBucket>(c, ww, bits, direct) : build_index_buckets<Bucket>(c, ww, bits, direct);
   if (rc) return rc;
-  uint64_t novf = 0;
-  HIPCHK(c, hipMemcpyAsync(&novf, tmp + nb, 8, hipMemcpyDeviceToHost, c->stream));
-  hipLaunchKernelGGL(k_index_ovf_set, dim3(nblk(nb, 256)), dim3(256), 0, c->stream, c->idx_T, nb, tmp);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(e2, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  B.release();  // 8 bytes per bucket: returned before the overflow array is allocated
-  c->idx_novf = novf;
-  if (c->idx_E_cap < novf + 16) {
-    if (c->idx_E) (void)hipFree(c->idx_E);
-    c->idx_E = nullptr;
-    c->idx_E_cap = 0;
-    HIPCHK(c, hipMalloc((void**)&c->idx_E, ((uint64_t)novf + 16) * sizeof(uint4)));
-    c->idx_E_cap = novf + 16;
-  }
-  HIPCHK(c, hipEventRecord(e3, c->stream));
-  if (c->nbases) {
-    hipLaunchKernelGGL(k_index<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->dbm2, c->seq_off, c->nseq,
-                       c->nbases, ww, bits, direct, c->wide, c->idx_T, c->idx_E);
-    HIPCHK(c, hipGetLastError());
-  }
-  HIPCHK(c, hipEventRecord(e1, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  float ms = 0, ms2 = 0;
-  (void)hipEventElapsedTime(&ms, e0, e2);
-  (void)hipEventElapsedTime(&ms2, e3, e1);
-  c->stats.ms_index_build = ms + ms2;
   c->idx_ww = ww;
   c->idx_bits = bits;
   c->idx_direct = direct;
@@ -834,7 +877,7 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
     size_t mfree = 0, mtotal = 0;
     HIPCHK(c, hipMemGetInfo(&mfree, &mtotal));
     const uint64_t have = (uint64_t)mfree + (c->ctx_T ? c->ctx_T_cap * sizeof(CtxBucket) : 0) +
-                          (c->ctx_E ? c->ctx_E_cap * sizeof(CtxEntry) : 0) + (c->idx_T ? c->idx_T_cap * sizeof(Bucket) : 0) +
+                          (c->ctx_E ? c->ctx_E_cap * sizeof(CtxEntry) : 0) + c->idx_T_bytes +
                           (c->idx_E ? c->idx_E_cap * sizeof(uint4) : 0);
     const uint64_t need = (nb + 1) * (sizeof(CtxBucket) + 12) + c->nbases / 3 * sizeof(CtxEntry) + (4ull << 30);
     if (need > have) return 100;
@@ -844,7 +887,7 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
   if (c->idx_E) (void)hipFree(c->idx_E);
   c->idx_T = nullptr;
   c->idx_E = nullptr;
-  c->idx_T_cap = c->idx_E_cap = 0;
+  c->idx_T_bytes = c->idx_E_cap = 0;
   c->ev_used = 0;
   hipEvent_t e0 = pool_event(c), e1 = pool_event(c), e2 = pool_event(c), e3 = pool_event(c);
   if (!e0 || !e1 || !e2 || !e3) return fail(c, 10, "hipEventCreate failed");
@@ -980,7 +1023,7 @@ static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
 // k_match_t runs, see reads_x_fit) and positions fit 32 bits.
 static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL) {
   if (const char* e = getenv("MUSC_INDEX"))
-    if (strcmp(e, "classic") == 0) return false;
+    if (!strcmp(e, "classic") || !strcmp(e, "lines") || !strcmp(e, "classic64")) return false;  // the two-kernel path
   // (the planes themselves may exist without an X: an all-zero one is made for the side that has
   // none when the other side does, and the database's stays for the context's lifetime)
   if (c->db_has_x) return false;
@@ -1660,7 +1703,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   c->stats.index_kind = (uint32_t)c->idx_kind;
   c->stats.index_bytes = c->idx_kind == 1
                              ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + (c->idx_novf + 16) * sizeof(CtxEntry)
-                             : ((1ull << c->idx_bits) + 1) * sizeof(Bucket) + (c->idx_novf + 16) * sizeof(uint4);
+                             : ((1ull << c->idx_bits) + 1) * (c->idx_lines ? sizeof(LineBucket) : sizeof(Bucket)) + (c->idx_novf + 16) * sizeof(uint4);
   if (c->idx_kind == 1)
     return match_ctx_pass(c, P, pp, block_mode, block_thr, max_matches, planned_batches, nhits);
 

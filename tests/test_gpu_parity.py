@@ -19,19 +19,21 @@ from cases import make_case, mutate, rand_seq
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "quad", "classic"])
+@pytest.fixture(scope="module", params=["auto", "quad", "classic", "lines"])
 def eng(request):
-    """Every test of this module runs three times: on what the library picks by itself (context
+    """Every test of this module runs four times: on what the library picks by itself (context
     buckets wherever the run fits them, matched by k_match_t -- comparisons in the lane that owns the
     read, kernels_match_lane.hpp), with MUSC_MATCH=quad (context buckets, k_match: the first fused
-    kernel, kept as a second implementation) and with MUSC_INDEX=classic (64-byte buckets, k_screen ->
-    k_confirm)."""
+    kernel, kept as a second implementation), with MUSC_INDEX=classic (the two-kernel path k_screen ->
+    k_confirm on the bucket layout the database's density selects: 64-byte buckets for these
+    small databases) and with MUSC_INDEX=lines (the two-kernel path on line buckets, the layout of
+    dense databases such as BASELINE config 5)."""
     from muscato_amd import Engine
     old = {k: os.environ.get(k) for k in ("MUSC_INDEX", "MUSC_MATCH")}
     os.environ.pop("MUSC_INDEX", None)
     os.environ.pop("MUSC_MATCH", None)
-    if request.param == "classic":
-        os.environ["MUSC_INDEX"] = "classic"
+    if request.param in ("classic", "lines"):
+        os.environ["MUSC_INDEX"] = request.param
     elif request.param == "quad":
         os.environ["MUSC_MATCH"] = "quad"
     e = Engine(0)
@@ -444,7 +446,7 @@ def test_low_complexity_stress(eng):
                                      literal.make_params(c, bloom_size=64_000_000, num_hash=6, nthreads=8))
     got = gpu_hits(eng, c, reads, targets, False)
     st = eng.stats()
-    assert st["index_kind"] == (0 if eng.index_mode == "classic" else 1)
+    assert st["index_kind"] == (0 if eng.index_mode in ("classic", "lines") else 1)
     assert (st["n_descriptors"] if st["index_kind"] == 0 else st["n_pairs"]) > 1_000_000 and len(got) > 500_000
     assert_same(got, exp)
     assert st["n_overflow_blocks"] == 0
