@@ -90,7 +90,11 @@ def variant(name: str, defines) -> str:
     out_dir = os.path.join(os.path.dirname(HERE), "build_variants")
     os.makedirs(out_dir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, False, False, defines if "match_lane" in s else (), "." + name if "match_lane" in s else ""), SOURCES))
+        # (-DMAIN... flags go to the main unit, everything else to the k_match_t units)
+        main_defs = [d[len("-DMAIN_"):].join(["-D", ""]) if False else "-D" + d[len("-DMAIN_"):] for d in defines if d.startswith("-DMAIN_")]
+        lane_defs = [d for d in defines if not d.startswith("-DMAIN_")]
+        objs = list(ex.map(lambda s: _compile(s, False, False, lane_defs if "match_lane" in s else main_defs,
+                                              "." + name if ("match_lane" in s and lane_defs) or ("match_lane" not in s and main_defs) else ""), SOURCES))
     out = os.path.join(out_dir, name + ".so")
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     return out

@@ -216,6 +216,38 @@ DEV int rec_count_dinuc16(const R& r, uint32_t q1, int ww) {
   return key_count_dinuc16((uint32_t)r.ext(2 * q1), ww);
 }
 
+// single-instruction forms the compiler does not pick by itself (it re-associates the chains for
+// instruction-level parallelism the kernel has no use for: it is bound by the number of vector
+// instructions it issues)
+DEV uint32_t bcnt_add(uint32_t x, uint32_t acc) {  // popcount(x) + acc
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+DEV uint32_t and_or(uint32_t a, uint32_t b, uint32_t c) {  // (a & b) | c
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+DEV uint32_t and_or_s(uint32_t a, uint32_t b, uint32_t c) {  // the same with b in a scalar register
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+// one bit per base at which two 2-bit streams differ (x = their XOR), under the mask m:
+// ((x | x >> 1) & m), the OR-AND as one v_bitop3
+DEV uint32_t base_diff(uint32_t x, uint32_t m) { return __builtin_amdgcn_bitop3_b32(x, x >> 1, m, 0xA8); }
+
+// utils/entropy.go:5-40 for a window of at most 16 bases without X: a dinucleotide is a 4-bit field
+// of the key; two instructions each (v_bfe_u32, v_lshl_or_b32)
+DEV int key_dinucs16(uint32_t key, int ww) {
+  uint32_t seen = 0;
+#pragma unroll
+  for (int i = 0; i < 15; i++)
+    if (i + 1 < ww) seen = (1u << __builtin_amdgcn_ubfe(key, 2 * i, 4)) | seen;
+  return __popc(seen);
+}
+
 // The read's IMAGE for window k: its bases moved to where the context stream holds the target
 // bases it is compared with -- the read shifted left by sh = 2 * (CL - q1) bits, eight words
 // (240 bits).  Phase A of k_match builds it once per (read, window); every comparison of the read

@@ -209,6 +209,9 @@ DEV uint32_t opaque(uint32_t x) {  // stops the compiler from keeping values der
 #ifndef SCR_ROUNDS
 #define SCR_ROUNDS 4  // quad rounds whose bucket loads are in flight together (8 per chunk)
 #endif
+#ifndef SCR_CU
+#define SCR_CU 4  // phase C: overflow entries a thread has in flight
+#endif
 #ifndef SCR_LROUNDS
 #define SCR_LROUNDS 8  // line buckets: rounds of eight lines whose loads are in flight together (16 per chunk)
 #endif
@@ -475,30 +478,47 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
         for (uint32_t e = 0; e < oc0 && pre + e < SCR_OWN; e++) s_own[pre + e] = (uint16_t)(2 * tidc);
         for (uint32_t e = 0; e < oc1 && pre + oc0 + e < SCR_OWN; e++) s_own[pre + oc0 + e] = (uint16_t)(2 * tidc + 1);
         lds_barrier();
-        for (uint32_t t0 = 0; t0 < total; t0 += TILE) {
-          const uint32_t t = t0 + tidc;
-          bool ok = t < total;
-          uint32_t seg = 0, z = 0;
-          uint4 ent = make_uint4(0, 0, 0, 0);
-          int k = k0, q1 = 0;
-          if (ok) {
-            if (t < SCR_OWN) {
-              seg = s_own[t];
-            } else {  // rare: largest seg with s_pref[seg] <= t
-              uint32_t lo = 0, hi = SCR_PROBES;
-              while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) / 2;
-                if (s_pref[mid] <= t) lo = mid; else hi = mid;
+        // SCR_CU items per thread and round: their loads are all issued before the first is tested --
+        // with one load in flight per lane a wave keeps 1 KB on its way and the whole GPU 4 MB, which
+        // at HBM latency is 2 TB/s however fast the tests are (measured on the cfg5 shard: 10 entries
+        // per probe, 2.2 TB/s of entries)
+        for (uint32_t t0 = 0; t0 < total; t0 += SCR_CU * TILE) {
+          uint32_t segs[SCR_CU];
+          uint4 ents[SCR_CU];
+          bool oks[SCR_CU];
+#pragma unroll
+          for (int u = 0; u < SCR_CU; u++) {
+            const uint32_t t = t0 + (uint32_t)u * TILE + tidc;
+            oks[u] = t < total;
+            segs[u] = 0;
+            ents[u] = make_uint4(0, 0, 0, 0);
+            if (oks[u]) {
+              uint32_t seg;
+              if (t < SCR_OWN) {
+                seg = s_own[t];
+              } else {  // rare: largest seg with s_pref[seg] <= t
+                uint32_t lo = 0, hi = SCR_PROBES;
+                while (hi - lo > 1) {
+                  const uint32_t mid = (lo + hi) / 2;
+                  if (s_pref[mid] <= t) lo = mid; else hi = mid;
+                }
+                seg = lo;
               }
-              seg = lo;
+              segs[u] = seg;
+              const u32x4_v te = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(E) + s_ovf[seg] + (t - s_pref[seg]));
+              ents[u] = make_uint4(te.x, te.y, te.z, te.w);
             }
-            const u32x4_v te = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(E) + s_ovf[seg] + (t - s_pref[seg]));
-            ent = make_uint4(te.x, te.y, te.z, te.w);
-            k = k0 + (int)(seg & 1u);
-            q1 = (seg & 1u) ? q1b : q1a;
-            ok = screen_entry_ok(ent, q1, pp.ww, s_rfl[seg], s_lenbud[seg], &z);
           }
-          append(ok, ent, seg, k, q1, z, false);
+#pragma unroll
+          for (int u = 0; u < SCR_CU; u++) {
+            if (u > 0 && t0 + (uint32_t)u * TILE >= total) break;  // uniform
+            const uint32_t seg = segs[u];
+            uint32_t z = 0;
+            const int k = k0 + (int)(seg & 1u), q1 = (seg & 1u) ? q1b : q1a;
+            bool ok = oks[u];
+            if (ok) ok = screen_entry_ok(ents[u], q1, pp.ww, s_rfl[seg], s_lenbud[seg], &z);
+            append(ok, ents[u], seg, k, q1, z, false);
+          }
         }
       }
       lds_barrier();  // the LDS tables are reused by the next chunk

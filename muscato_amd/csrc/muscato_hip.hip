@@ -42,6 +42,7 @@
 #include "kernels_confirm.hpp"
 #include "kernels_match.hpp"
 #include "kernels_match_lane_inst.hpp"  // k_match_t: declaration only (defined in match_lane_rw*.hip)
+#include "kernels_screen_lane.hpp"
 MUSC_LANE_INSTANCES(extern, 4)
 MUSC_LANE_INSTANCES(extern, 8)
 MUSC_LANE_INSTANCES(extern, 12)
@@ -177,6 +178,8 @@ struct musc_ctx {
   Bucket* idx_T = nullptr;  // 2^idx_bits buckets: 64-byte Bucket, or (idx_lines) 128-byte LineBucket
   uint4* idx_E = nullptr;   // overflow entries
   bool idx_lines = false;   // the table holds line buckets (kernels_index.hpp)
+  unsigned scrt_resident = 0;  // k_screen_t: waves resident at once (queried once per record stride)
+  int scrt_rw = 0;
   uint64_t idx_T_bytes = 0, idx_E_cap = 0;  // allocated table bytes / entries (kept across rebuilds:
                                             // hipMalloc / hipFree of tens of GiB take seconds)
   uint64_t idx_n = 0;       // indexed window starts
@@ -472,11 +475,48 @@ int check_params(musc_ctx* c, const musc_params* P) {
   return 0;
 }
 
+// line buckets without X anywhere, record strides k_screen_t is built for: the wave-autonomous screen
+// (kernels_screen_lane.hpp); MUSC_SCREEN=wg keeps k_screen (A/B runs)
+bool screen_lane(const musc_ctx* c, bool mask) {
+  const char* se = getenv("MUSC_SCREEN");
+  return c->idx_lines && !mask && !c->rdm && (c->rw == 4 || c->rw == 8 || c->rw == 12 || c->rw == 16) && !(se && !strcmp(se, "wg"));
+}
+
+// workgroups of the screen stage: the descriptor buffer is cut into that many regions.  k_screen_t's
+// workgroups are single waves that stay for the whole launch: as many as are resident at once (a
+// second, thinner round of them would cost what a full one does).
+unsigned screen_grid(musc_ctx* c, uint32_t n, bool mask) {
+  unsigned g = std::min(nblk(n, TILE), MAX_GRID);
+  if (screen_lane(c, mask)) {
+    if (!c->scrt_resident) {
+      int per_cu = 0, ncu = 0;
+      const void* fn = c->rw == 4 ? reinterpret_cast<const void*>(&k_screen_t<4>) : c->rw == 8 ? reinterpret_cast<const void*>(&k_screen_t<8>)
+                       : c->rw == 12 ? reinterpret_cast<const void*>(&k_screen_t<12>) : reinterpret_cast<const void*>(&k_screen_t<16>);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 8; }
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+      c->scrt_resident = (unsigned)per_cu * (unsigned)ncu;
+      c->scrt_rw = c->rw;
+    }
+    if (c->scrt_rw != c->rw) { c->scrt_resident = 0; return screen_grid(c, n, mask); }
+    g = std::min(g, std::min(c->scrt_resident, MAX_GRID));
+  }
+  return g;
+}
+
 template <int RW>
 void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, const PathParams& pp) {
   const dim3 block(TILE);
   if (stage == 0) {
-    const dim3 sgrid(std::min(nblk(n, TILE), MAX_GRID));
+    const dim3 sgrid(screen_grid(c, n, mask));
+    if constexpr (RW == 4 || RW == 8 || RW == 12 || RW == 16) {
+      if (screen_lane(c, mask)) {
+        hipLaunchKernelGGL((k_screen_t<RW>), sgrid, dim3(64), 0, c->stream, c->rd, r0, n, c->d_pp, c->nmiss_tab.p,
+                           reinterpret_cast<const LineBucket*>(c->idx_T), c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,
+                           c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
+                           c->counters + 8);
+        return;
+      }
+    }
 #define MUSC_LAUNCH_SCREEN(M, O)                                                                                  \
     do { if (c->idx_lines) MUSC_LAUNCH_SCREEN2(M, O, true); else MUSC_LAUNCH_SCREEN2(M, O, false); } while (0)
 #define MUSC_LAUNCH_SCREEN2(M, O, LN)                                                                             \
@@ -1795,7 +1835,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       total = c->h_pinned[4];
       const uint64_t hits_so_far = c->h_pinned[8];
-      const uint64_t sgrid = std::min(nblk(n, TILE), MAX_GRID);
+      const uint64_t sgrid = screen_grid(c, n, mask);
       const uint64_t need = c->h_pinned[7] * sgrid;  // every workgroup region as large as the fullest
       if (need > PAIR_CAP) {
         // too many pairs for one launch: retry this range with half the reads
