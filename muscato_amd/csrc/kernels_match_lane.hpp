@@ -281,12 +281,12 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   // pair's result word (NX_REJECT, or nmiss | NX_DUP | NX_ACC0 | window << 20 | slot << 24).
   auto score = [&](bool live, int k, int q1, const uint32_t (&img)[8], const WinTab& tb, const uint32_t (&xm)[8], uint32_t jx,
                    const uint32_t (&c)[8], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
-    // placements past the target's first bases (p = jx - q1 > 0) only have to end inside the target;
-    // the pos-0 rules are evaluated only when some lane of the wave is at p <= 0
+    // a placement must start inside the target (p = jx - q1 >= 0) and end inside it; the pos-0 rules
+    // (ctx_fit) are evaluated only when some lane of the wave is at p == 0 or at target position 0
     uint32_t z = 0;
     bool ok;
-    if (__any(live && jx <= (uint32_t)q1)) ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
-    else ok = live & (len - q1 <= (int)(c[7] >> 16));
+    if (__any(live && (jx == (uint32_t)q1 || jx == 0u))) ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
+    else ok = live & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[7] >> 16));
     ncmp += ok ? 1u : 0u;
     uint32_t w = NX_REJECT;
     if (ok) {
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         }
         uint32_t z = 0;
         bool ok;
-        if (__any(have && jx <= (uint32_t)q1)) ok = have & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
-        else ok = have & (len - q1 <= (int)(c[7] >> 16));
+        if (__any(have && (jx == (uint32_t)q1 || jx == 0u))) ok = have & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
+        else ok = have & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[7] >> 16));
         ncmp += ok ? 1u : 0u;
         uint32_t w = NX_REJECT;
         if (ok) {
@@ -708,6 +708,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(rlen);
       ulen = __ballot(active && (uint32_t)rlen != len0) == 0 ? len0 : 0xFFFFFFFFu;
 
+      uint3* const list_cur = s_list[par][wid];  // (formed once per wave-tile: its address arithmetic is two multiplies)
       // a reported candidate of the lane's own read (in-lane comparisons): appended in lane order
       auto report_own = [&](uint32_t w, uint32_t gene, uint32_t pos, uint32_t& wck) __attribute__((always_inline)) {
         const bool acc = w != NX_REJECT;
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint32_t v = w & 0xFFFFu;
         best = v < best ? v : best;
         if (slot < MATCHT_WLIST) {
-          s_list[par][wid][slot] = make_uint3(w, gene, pos);
+          list_cur[slot] = make_uint3(w, gene, pos);
         } else if (slot - MATCHT_WLIST < sregion) {
           spill[sregion0 + (slot - MATCHT_WLIST)] = make_uint4(w, gene, pos, 0u);
         }
