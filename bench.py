@@ -456,7 +456,7 @@ def main() -> int:
                                   "what": "sized pass + tuples copied to pinned host memory (no read upload)"}
         legs["pcie_inclusive"]["reads_per_s"] = wl.n_raw_reads / (legs["pcie_inclusive"]["ms_per_step"] / 1e3)
 
-        if st["index_kind"] == 1:
+        if st["index_kind"] in (1, 2):
             # (1b) the same sized pass replayed as one hipGraph launch (MUSC_GRAPH=1, opt-in): what is
             # left of the host's share once the seven launches per batch are one
             os.environ["MUSC_GRAPH"] = "1"
@@ -592,7 +592,7 @@ def main() -> int:
         dominant = screen_roof if acc["ms_screen"] >= acc["ms_confirm"] else confirm_roof
         kind = st["index_kind"]
         match_roof = None
-        if kind == 1:
+        if kind in (1, 2):
             # k_match (context buckets): screen + confirm + select in one kernel.  A launch loads every
             # read's record, ONE 128-byte bucket line per (read, window) probe -- the line carries the
             # placements' target bases, there is no target gather -- the overflow entries it walks, and
@@ -615,11 +615,11 @@ def main() -> int:
                 "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
                 "traffic": measured_traffic(tkey, kname) if not args.reads else None,
                 "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc passes of this command, recorded; not measured by this run)",
-                "algorithmic_bytes": "%d B per read record + 128 B bucket line per probe + 40 B per overflow entry walked + "
-                                     "16 B per tuple staged" % rec_b,
+                "algorithmic_bytes": "%d B per read record + 128 B bucket line per probe + %d B per overflow entry walked + "
+                                     "16 B per tuple staged" % (rec_b, 60 if kind == 2 else 40),
                 "bytes_per_launch": b_m,
                 "achieved_strict": ach_s, "frac_strict": ach_s / HBM_PEAK_GBS,
-                "strict_note": "a probe billed only for what it uses of its line: 8 B header + 40 B per index entry present",
+                "strict_note": "a probe billed only for what it uses of its line: 8 B header + %d B per index entry present" % (60 if kind == 2 else 40),
                 "reads_per_launch": st["n_reads"] / nlm, "probes_per_launch": st["n_read_windows"] / nlm,
                 "entries_per_launch": st["n_candidates"] / nlm, "overflow_entries_per_launch": st["n_overflow_entries"] / nlm,
                 "compared_per_launch": st["n_pairs"] / nlm, "tuples_per_launch": st["n_hits"] / nlm,
@@ -644,7 +644,9 @@ def main() -> int:
                                 + ", repeat passes over the same reads (no sizing round trips); SURVEY 8d's "
                                   "pinned-host-to-pinned-host scope is `survey_scope`, a pass over fresh reads `first_pass_ms`",
             },
-            "index": {"kind": "context buckets (128 B, fused k_match_t)" if kind == 1 else "64-byte buckets (k_screen -> k_confirm)",
+            "index": {"kind": "context buckets (128 B: 3 x 120 bases, fused k_match_t)" if kind == 1
+                      else "wide context buckets (128 B: 2 x 200 bases, fused k_match_t)" if kind == 2
+                      else "window-start buckets (k_screen -> k_confirm)",
                       "bytes": st["index_bytes"]},
             "roofline": dominant, "roofline_confirm": confirm_roof, "roofline_screen": screen_roof,
             "per_step": {

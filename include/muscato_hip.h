@@ -111,14 +111,15 @@ typedef struct {
                              * when two windows of the read found it (then it is two pairs);
                              * 0 with context buckets (no descriptors exist)               */
   /* ---- since ABI version 2 */
-  uint32_t index_kind;      /* index the pass ran on: 0 = 64-byte buckets + target gather
-                             * (k_screen -> k_confirm), 1 = context buckets (k_match_d or
-                             * k_match)                                                     */
+  uint32_t index_kind;      /* index the pass ran on: 0 = window-start buckets + target gather
+                             * (k_screen -> k_confirm), 1 = context buckets, 120 bases
+                             * (k_match_t or k_match), 2 = wide context buckets, 200 bases
+                             * (k_match_t)                                                  */
   uint32_t match_launches;  /* launches of that kernel (index_kind 1)                       */
   uint64_t n_overflow_entries; /* index entries beyond a bucket's inline ones that were walked */
   uint64_t match_bytes;     /* algorithmic bytes of those launches: record (ceil(2L/8) B)
-                             * per read + one 128-B bucket line per probe + 40 B per overflow
-                             * entry walked + 16 B per tuple staged                         */
+                             * per read + one 128-B bucket line per probe + 40 B (wide: 60)
+                             * per overflow entry walked + 16 B per tuple staged                         */
   uint64_t match_bytes_strict; /* the same with a probe billed for what it uses of its line:
                              * 8 B header + 40 B per inline entry present                   */
   uint64_t index_bytes;     /* device memory held by the index (table + overflow entries)  */

@@ -12,7 +12,8 @@ LIB = os.path.join(HERE, "libmuscato_hip.so")
 OBJ = os.path.join(HERE, "build")
 # one translation unit for the host side and most kernels, and one per record stride for k_match_t
 # (kernels_match_lane_inst.hpp): they compile side by side
-SOURCES = [os.path.join(CSRC, f) for f in ("muscato_hip.hip", "match_lane_rw4.hip", "match_lane_rw8.hip", "match_lane_rw12.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("muscato_hip.hip", "match_lane_rw4.hip", "match_lane_rw8.hip", "match_lane_rw12.hip",
+                                           "match_lane_rw8w.hip", "match_lane_rw12w.hip", "match_lane_rw16w.hip")]
 HEADERS = [os.path.join(os.path.dirname(HERE), "include", "muscato_hip.h")] + \
     [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
 LANE_ONLY = os.path.join(CSRC, "kernels_match_lane.hpp")  # k_match_t's definition: muscato_hip.hip sees its declaration only

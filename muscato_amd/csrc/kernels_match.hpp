@@ -43,6 +43,26 @@ struct CtxEntry {  // overflow entry, 40 bytes (8-byte aligned)
 };
 static_assert(sizeof(CtxEntry) == 40, "overflow entries are packed");
 
+// WIDE context buckets: the same line with TWO inline entries of 60 bytes -- target number, window
+// position and CTXW_BASES = 200 target bases (400 bits: words 0..11 and the low half of word 12;
+// the high half of word 12: distance to the target end) -- for runs that do not fit 120 bases of
+// context: Windows 0,20,40 with 100-bp reads need 140, two windows with 150-bp reads 170.  Entries
+// beyond a bucket's second live in E as 60-byte CtxEntryW.  Matched by k_match_t only.
+#define CTXW_BASES 200
+#define CTXW_INLINE 2
+#define CTXW_WORDS 13
+struct CtxEntryW {
+  uint32_t gene, jx;
+  uint32_t ctx[CTXW_WORDS];
+};
+static_assert(sizeof(CtxEntryW) == 60, "wide entries are packed");
+struct __attribute__((aligned(128))) CtxBucketW {
+  uint32_t count;
+  uint32_t ovf;
+  CtxEntryW e[CTXW_INLINE];
+};
+static_assert(sizeof(CtxBucketW) == 128, "a wide context bucket is one cache line");
+
 // 64 bits of the stream from a possibly negative bit offset (zeros before the stream start)
 DEV uint64_t ext64s(const uint32_t* __restrict__ w, long long bo) {
   if (bo >= 0) return ext64(w, (uint64_t)bo);
@@ -50,24 +70,26 @@ DEV uint64_t ext64s(const uint32_t* __restrict__ w, long long bo) {
   return ext64(w, 0) << (uint32_t)(-bo);
 }
 
-// the eight context words of the window starting at global base g of a target that ends at base `e`
-DEV void ctx_words(const uint32_t* __restrict__ db2, uint64_t g, uint64_t e, int CL, uint32_t (&c)[8]) {
+// the NW context words of the window starting at global base g of a target that ends at base `e`: the
+// bases [g - CL, ...) as a 2-bit stream, its last half word replaced by the distance to the target end
+template <int NW>
+DEV void ctx_words(const uint32_t* __restrict__ db2, uint64_t g, uint64_t e, int CL, uint32_t (&c)[NW]) {
   const long long bo = 2 * ((long long)g - (long long)CL);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < (NW + 1) / 2; i++) {
     const uint64_t v = ext64s(db2, bo + 64 * i);
     c[2 * i] = (uint32_t)v;
-    c[2 * i + 1] = (uint32_t)(v >> 32);
+    if (2 * i + 1 < NW) c[2 * i + 1] = (uint32_t)(v >> 32);
   }
   const uint64_t rem = e - g;
-  c[7] = (c[7] & 0xFFFFu) | ((uint32_t)(rem > 65535 ? 65535 : rem) << 16);
+  c[NW - 1] = (c[NW - 1] & 0xFFFFu) | ((uint32_t)(rem > 65535 ? 65535 : rem) << 16);
 }
 
-template <bool SCATTER>
+template <bool SCATTER, bool WIDE>
 __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ db2,
                                                    const uint64_t* __restrict__ seq_off, uint32_t nseq,
                                                    uint64_t nbases, int ww, int bits, int direct, int CL,
-                                                   CtxBucket* __restrict__ T, CtxEntry* __restrict__ E,
+                                                   CtxBucket* __restrict__ T, void* __restrict__ Ev,
                                                    uint32_t* __restrict__ cursor) {
   __shared__ uint32_t s_g0;
   const uint64_t nchunks = (nbases + blockDim.x - 1) / blockDim.x;
@@ -95,30 +117,45 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
       atomicAdd(&T[b].count, 1u);
     } else {
       const uint32_t slot = atomicAdd(&cursor[b], 1u);
-      uint32_t c[8];
-      ctx_words(db2, g, e, CL, c);
-      if (slot < CTX_INLINE) {
-        T[b].gene[slot] = gene;
-        T[b].jx[slot] = (uint32_t)jx;
-        uint4* dst = reinterpret_cast<uint4*>(T[b].ctx[slot]);
-        dst[0] = make_uint4(c[0], c[1], c[2], c[3]);
-        dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
-      } else {
-        CtxEntry* p = E + ((uint64_t)T[b].ovf + (slot - CTX_INLINE));
-        p->gene = gene;
-        p->jx = (uint32_t)jx;
+      if constexpr (WIDE) {
+        CtxBucketW* const TW = reinterpret_cast<CtxBucketW*>(T);
+        CtxEntryW ent;
+        ent.gene = gene;
+        ent.jx = (uint32_t)jx;
+        ctx_words<CTXW_WORDS>(db2, g, e, CL, ent.ctx);
+        CtxEntryW* p = slot < CTXW_INLINE ? &TW[b].e[slot] : reinterpret_cast<CtxEntryW*>(Ev) + ((uint64_t)TW[b].ovf + (slot - CTXW_INLINE));
+        uint32_t* pw = reinterpret_cast<uint32_t*>(p);
+        pw[0] = ent.gene;
+        pw[1] = ent.jx;
 #pragma unroll
-        for (int i = 0; i < 8; i++) p->ctx[i] = c[i];
+        for (int i = 0; i < CTXW_WORDS; i++) pw[2 + i] = ent.ctx[i];
+      } else {
+        CtxEntry* const E = reinterpret_cast<CtxEntry*>(Ev);
+        uint32_t c[8];
+        ctx_words<8>(db2, g, e, CL, c);
+        if (slot < CTX_INLINE) {
+          T[b].gene[slot] = gene;
+          T[b].jx[slot] = (uint32_t)jx;
+          uint4* dst = reinterpret_cast<uint4*>(T[b].ctx[slot]);
+          dst[0] = make_uint4(c[0], c[1], c[2], c[3]);
+          dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
+        } else {
+          CtxEntry* p = E + ((uint64_t)T[b].ovf + (slot - CTX_INLINE));
+          p->gene = gene;
+          p->jx = (uint32_t)jx;
+#pragma unroll
+          for (int i = 0; i < 8; i++) p->ctx[i] = c[i];
+        }
       }
     }
   }
 }
 
-MUSC_KERNEL void k_ctx_ovf_count(const CtxBucket* __restrict__ T, uint64_t nb, uint64_t* __restrict__ tmp) {
+MUSC_KERNEL void k_ctx_ovf_count(const CtxBucket* __restrict__ T, uint64_t nb, uint32_t n_inline, uint64_t* __restrict__ tmp) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb) {
-    const uint32_t c = T[b].count;
-    tmp[b] = c > CTX_INLINE ? c - CTX_INLINE : 0u;
+    const uint32_t c = T[b].count;  // (count and ovf sit in the first eight bytes of either bucket layout)
+    tmp[b] = c > n_inline ? c - n_inline : 0u;
   } else if (b == nb) {
     tmp[b] = 0;
   }
@@ -148,9 +185,10 @@ struct MatchParams {
   // need[k] = the windows whose exactness a comparison through window k has to establish: the
   // ones before k (first-window rule) and k itself when the table is hashed (a direct table's
   // bucket is the key: the probed window matches by construction).
+  // (rows of CTXW_WORDS words: wide context buckets use them all, the 120-base ones the first eight)
   uint32_t need[CTX_MAX_W];
-  uint32_t wm[CTX_MAX_W][CTX_MAX_W][8];
-  uint32_t lm[CTX_BASES + 1][CTX_MAX_W][8];
+  uint32_t wm[CTX_MAX_W][CTX_MAX_W][CTXW_WORDS];
+  uint32_t lm[CTXW_BASES + 1][CTX_MAX_W][CTXW_WORDS];
 };
 
 // bits [lo, hi) of a 32-bit word as a mask, for any int lo / hi (host and device)
@@ -169,10 +207,10 @@ inline void match_tables(MatchParams& mp) {
     const int sh = 2 * (mp.CL - mp.win[k]);
     mp.need[k] = ((1u << k) - 1u) | (mp.direct ? 0u : (1u << k));
     for (int kk = 0; kk < mp.W; kk++)
-      for (int j = 0; j < 8; j++)
+      for (int j = 0; j < CTXW_WORDS; j++)
         mp.wm[k][kk][j] = bit_range_mask(sh + 2 * mp.win[kk] - 32 * j, sh + 2 * (mp.win[kk] + mp.ww) - 32 * j);
-    for (int len = 0; len <= CTX_BASES; len++)
-      for (int j = 0; j < 8; j++) mp.lm[len][k][j] = 0x55555555u & bit_range_mask(sh - 32 * j, sh + 2 * len - 32 * j);
+    for (int len = 0; len <= CTXW_BASES; len++)
+      for (int j = 0; j < CTXW_WORDS; j++) mp.lm[len][k][j] = 0x55555555u & bit_range_mask(sh - 32 * j, sh + 2 * len - 32 * j);
   }
 }
 
@@ -841,43 +879,51 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
 // ------------------------------------------------------------------------------------
 // Reads with X on context buckets (k_match_t, RX): with an X-free database an X in a read is a mismatch wherever
 // the read is placed, and a window holding one never finds its key in the index.  What the kernel
-// needs of a read's X is where they are: xpos = up to four positions (7 bits each, bits 0-27) and
-// their number (bits 28-31, saturating at 15).  A read with more than four X takes part only if
-// that many mismatches exceed its budget anyway -- then it has no tuples at all (k_xpos_check
+// needs of a read's X is where they are: xpos = a few positions from bit 0 up and their number (bits
+// 28-31, saturating at 15) -- four positions of 7 bits for the 120-base buckets, three of 8 bits for
+// the wide ones (reads of up to 200 bases).  A read with more X than its word lists takes part
+// only if that many mismatches exceed its budget anyway -- then it has no tuples at all (k_xpos_check
 // makes the run take the two-kernel path otherwise).
-#define XPOS_MAX 4
 #define XPOS_CNT(w) ((w) >> 28)
-#define XPOS_AT(w, q) (((w) >> (7 * (q))) & 127u)
+template <bool WIDE>
+struct XPos {
+  static constexpr uint32_t MAX = WIDE ? 3u : 4u, BITS = WIDE ? 8u : 7u;
+  __host__ __device__ static uint32_t at(uint32_t w, uint32_t q) { return (w >> (BITS * q)) & ((1u << BITS) - 1u); }
+};
 
-MUSC_KERNEL void k_read_xpos(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm, uint64_t nreads, int rw,
+template <bool WIDE>
+__global__ void k_read_xpos(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ rdm, uint64_t nreads, int rw,
                             uint32_t* __restrict__ xpos) {
+  typedef XPos<WIDE> XP;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nreads) return;
   uint32_t w = 0;
   if (rd[(i + 1) * rw - 1] & READ_HAS_X) {
     uint32_t cnt = 0;
+    bool far = false;  // an X beyond what a position field holds: the read counts as "too many to list"
     for (int j = 0; j < rw - 1; j++) {
       uint32_t m = rdm[i * rw + j] & 0x55555555u;
       while (m) {
         const uint32_t b = (uint32_t)__ffs(m) - 1u;
         m &= m - 1u;
         const uint32_t p = 16u * (uint32_t)j + (b >> 1);
-        if (cnt < XPOS_MAX && p < 128u) w |= p << (7u * cnt);
+        if (p >= (1u << XP::BITS)) far = true;
+        else if (cnt < XP::MAX) w |= p << (XP::BITS * cnt);
         cnt++;
       }
     }
-    w |= (cnt > 15u ? 15u : cnt) << 28;
+    w |= ((cnt > 15u || far) ? 15u : cnt) << 28;
   }
   xpos[i] = w;
 }
 
-// *bad = 1 if some read holds more than XPOS_MAX X and that many mismatches are within its budget
+// *bad = 1 if some read holds more X than its word lists and that many mismatches are within its budget
 MUSC_KERNEL void k_xpos_check(const uint32_t* __restrict__ rd, const uint32_t* __restrict__ xpos, uint64_t nreads, int rw,
-                             const uint16_t* __restrict__ nmiss_tab, uint32_t max_len, uint32_t* __restrict__ bad) {
+                             const uint16_t* __restrict__ nmiss_tab, uint32_t max_len, uint32_t xmax, uint32_t* __restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nreads) return;
   const uint32_t cnt = XPOS_CNT(xpos[i]);
-  if (cnt <= XPOS_MAX) return;
+  if (cnt <= xmax) return;
   const uint32_t len = rd[(i + 1) * rw - 1] & 0xFFFFu;
   const uint32_t budget = len <= max_len ? nmiss_tab[len] : 0xFFFFu;
   if (cnt == 15u || cnt <= budget) atomicOr(bad, 1u);

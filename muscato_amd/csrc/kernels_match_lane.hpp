@@ -49,7 +49,33 @@
 #pragma once
 #include "kernels_match_lane_inst.hpp"
 
-template <int RW, int W, bool RX>
+// The read's image for a window: the record shifted left by sh bits (wave-uniform), NW words -- read_image
+// of kernels_match.hpp for either context width
+template <int RW, int NW>
+DEV void read_image_n(const Rec<RW>& rec, uint32_t sh, uint32_t (&img)[NW]) {
+  const uint32_t bs = sh & 31u;
+#define MUSC_IMG_W(Q) (((Q) >= 0 && (Q) < RW - 1) ? rec.w[((Q) >= 0 && (Q) < RW - 1) ? (Q) : 0] : 0u)
+#define MUSC_IMG_CASE(WO)                                                  \
+  case WO:                                                                 \
+    _Pragma("unroll") for (int j = 0; j < NW; j++) {                       \
+      const uint32_t hi = MUSC_IMG_W(j - WO), lo = MUSC_IMG_W(j - WO - 1); \
+      img[j] = bs ? ((hi << bs) | (lo >> (32u - bs))) : hi;                \
+    }                                                                      \
+    break;
+  switch (__builtin_amdgcn_readfirstlane((int)(sh >> 5))) {
+    MUSC_IMG_CASE(0) MUSC_IMG_CASE(1) MUSC_IMG_CASE(2) MUSC_IMG_CASE(3)
+    MUSC_IMG_CASE(4) MUSC_IMG_CASE(5) MUSC_IMG_CASE(6) MUSC_IMG_CASE(7)
+    MUSC_IMG_CASE(8) MUSC_IMG_CASE(9) MUSC_IMG_CASE(10) MUSC_IMG_CASE(11) MUSC_IMG_CASE(12)
+    default:
+#pragma unroll
+      for (int j = 0; j < NW; j++) img[j] = 0u;
+      break;
+  }
+#undef MUSC_IMG_CASE
+#undef MUSC_IMG_W
+}
+
+template <int RW, int W, bool RX, bool WIDE>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
@@ -66,6 +92,12 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
                                                                 const uint32_t* __restrict__ rdx) {
   static_assert(W >= 1 && W <= CTX_MAX_W, "context buckets serve at most CTX_MAX_W windows");
   constexpr int NWAVE = TILE / 64;
+  // the bucket layout: three inline entries with 8 context words (120 bases), or -- WIDE -- two with 13 (200 bases)
+  constexpr int NIN = WIDE ? CTXW_INLINE : CTX_INLINE;
+  typedef XPos<WIDE> XP;  // how a read's xpos word lists its X
+  constexpr int NW = WIDE ? CTXW_WORDS : 8;
+  constexpr int NQ = WIDE ? 3 : 2;       // an overflow entry (gene, jx, ctx[NW]) = NQ 16-byte pieces + NT words
+  constexpr int NT = WIDE ? 3 : 2;
   // block_mode != 0: 2 (tile parity) x NWAVE x W x 64 counters of the overflow passes, then (mode 1) the sketch
   extern __shared__ uint32_t s_dyn[];
   __shared__ uint4 s_line[NWAVE][64 * 8];                 // the window's 64 bucket lines, swizzled
@@ -125,13 +157,13 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     if constexpr (RX) {
       if (active && rec.has_x()) xw = rdx[r0 + wt * WT + lane];
       const uint32_t xc = XPOS_CNT(xw);
-      if (xc > XPOS_MAX) xwin = 0xFFFFFFFFu;
+      if (xc > XP::MAX) xwin = 0xFFFFFFFFu;
 #pragma unroll
       for (int k = 0; k < W; k++) {
         const uint32_t q1 = (uint32_t)win[k];
 #pragma unroll
-        for (int q = 0; q < XPOS_MAX; q++)
-          if ((uint32_t)q < xc && XPOS_AT(xw, q) - q1 < (uint32_t)ww) xwin |= 1u << k;
+        for (int q = 0; q < (int)XP::MAX; q++)
+          if ((uint32_t)q < xc && XP::at(xw, q) - q1 < (uint32_t)ww) xwin |= 1u << k;
       }
     }
     if (ww <= 16 && direct) {
@@ -235,9 +267,9 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   //   need  the windows whose exactness the comparison has to establish (first-window rule), and
   //   wm    their masks
   struct WinTab {
-    uint32_t lm[8];
+    uint32_t lm[NW];
     uint32_t need;
-    uint32_t wm[W][8];
+    uint32_t wm[W][NW];
   };
   auto win_tab = [&](uint32_t ul, int k, uint32_t sh, uint32_t len, WinTab& tb) __attribute__((always_inline)) {
     tb.need = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp->need[k]);
@@ -245,30 +277,30 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     for (int kk = 0; kk < W; kk++) {
       const uint32_t* __restrict__ row = mp->wm[k][kk];
 #pragma unroll
-      for (int j = 0; j < 8; j++) tb.wm[kk][j] = kk <= k ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row[j]) : 0u;  // (need[k] has no window beyond k)
+      for (int j = 0; j < NW; j++) tb.wm[kk][j] = kk <= k ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row[j]) : 0u;  // (need[k] has no window beyond k)
     }
     if (ul != 0xFFFFFFFFu) {
       const uint32_t* __restrict__ row = mp->lm[__builtin_amdgcn_readfirstlane((int)ul)][k];
 #pragma unroll
-      for (int j = 0; j < 8; j++) tb.lm[j] = row[j];
+      for (int j = 0; j < NW; j++) tb.lm[j] = row[j];
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; j++) tb.lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
+      for (int j = 0; j < NW; j++) tb.lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
     }
   };
   // the X of a read in the image's coordinates
-  auto x_mask = [&](uint32_t xw, uint32_t sh, uint32_t (&xm)[8]) __attribute__((always_inline)) {
+  auto x_mask = [&](uint32_t xw, uint32_t sh, uint32_t (&xm)[NW]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) xm[j] = 0;
+    for (int j = 0; j < NW; j++) xm[j] = 0;
     if constexpr (RX) {
       if (__any(xw != 0)) {
         const uint32_t xc = XPOS_CNT(xw);
 #pragma unroll
-        for (int q = 0; q < XPOS_MAX; q++) {
-          const uint32_t b = sh + 2u * XPOS_AT(xw, q);
+        for (int q = 0; q < (int)XP::MAX; q++) {
+          const uint32_t b = sh + 2u * XP::at(xw, q);
           const uint32_t bit = (uint32_t)q < xc ? 1u << (b & 31u) : 0u;
 #pragma unroll
-          for (int j = 0; j < 8; j++) xm[j] |= (b >> 5) == (uint32_t)j ? bit : 0u;
+          for (int j = 0; j < NW; j++) xm[j] |= (b >> 5) == (uint32_t)j ? bit : 0u;
         }
       }
     }
@@ -279,21 +311,21 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   // from the same mismatch mask, which windows of the read match the target exactly here (the pair is
   // reported through the first of them only).  slot = the read's slot in its wave-tile.  Returns the
   // pair's result word (NX_REJECT, or nmiss | NX_DUP | NX_ACC0 | window << 20 | slot << 24).
-  auto score = [&](bool live, int k, int q1, const uint32_t (&img)[8], const WinTab& tb, const uint32_t (&xm)[8], uint32_t jx,
-                   const uint32_t (&c)[8], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
+  auto score = [&](bool live, int k, int q1, const uint32_t (&img)[NW], const WinTab& tb, const uint32_t (&xm)[NW], uint32_t jx,
+                   const uint32_t (&c)[NW], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
     // a placement must start inside the target (p = jx - q1 >= 0) and end inside it; the pos-0 rules
     // (ctx_fit) are evaluated only when some lane of the wave is at p == 0 or at target position 0
     uint32_t z = 0;
     bool ok;
-    if (__any(live && (jx == (uint32_t)q1 || jx == 0u))) ok = live & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
-    else ok = live & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[7] >> 16));
+    if (__any(live && (jx == (uint32_t)q1 || jx == 0u))) ok = live & ctx_fit(jx, c[NW - 1] >> 16, q1, ww, len, &z);
+    else ok = live & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[NW - 1] >> 16));
     ncmp += ok ? 1u : 0u;
     uint32_t w = NX_REJECT;
     if (ok) {
-      uint32_t d[8], nx = 0;
+      uint32_t d[NW], nx = 0;
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        // (lm has no bit in the high half of word 7, where the context keeps the distance to the target end)
+      for (int j = 0; j < NW; j++) {
+        // (lm has no bit in the high half of the last word, where the context keeps the distance to the target end)
         const uint32_t x = img[j] ^ c[j];
         d[j] = RX ? ((x | (x >> 1)) | xm[j]) & tb.lm[j] : base_diff(x, tb.lm[j]);
         nx = bcnt_add(d[j], nx);
@@ -304,7 +336,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         if (kk > k || !((tb.need >> kk) & 1u)) continue;  // wave-uniform
         uint32_t acc = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc = and_or_s(d[j], tb.wm[kk][j], acc);
+        for (int j = 0; j < NW; j++) acc = and_or_s(d[j], tb.wm[kk][j], acc);
         if (acc) exact &= ~(1u << kk);
       }
       // the reference's confirm for window k accepts the pair (it counts towards that window-key
@@ -338,14 +370,18 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   for (int k = 0; k < W; k++) wc_prev[k] = oc_prev[k] = ovf_prev[k] = 0, bb_prev[k] = WB_NONE;
   // the first 64 overflow entries of prev, a lane per entry: which probe (window, read slot), the read's
   // meta / xpos words and record (taken along when the entry was listed), and the entry itself as
-  // its three loads deliver it (gene, jx, ctx[0..1] | ctx[2..5] | ctx[6..7]): the loads' destination
+  // its loads deliver it (gene, jx, ctx[0..1] | ctx[2..5] | ... | the last two or three words): the loads' destination
   // registers are carried to the pass as they are -- any re-packing would be a copy that waits for
   // the data
   uint32_t o_n = 0, o_k = 0, o_seg = 0, o_meta = 0, o_xw = 0;
   Rec<RW> o_rec;
   o_rec.zero();
-  u32x4_u o_a = {0, 0, 0, 0}, o_b = {0, 0, 0, 0};
-  uint2 o_d = make_uint2(0, 0);
+  u32x4_u o_q[NQ];
+  uint32_t o_t[NT];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) o_q[q] = u32x4_u{0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < NT; q++) o_t[q] = 0;
 
   // phase A of a wave-tile plus what its lanes keep of it: the meta word (length | budget << 17 | valid
   // windows << 24); the record itself goes to s_rec[p]
@@ -421,15 +457,21 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     // belongs to (window ek, read slot seg) and that read's meta / xpos words and record; the first
     // n_items lanes hold one.  Candidates go to the lists of parity p.
     auto entry_compare = [&](uint32_t p, uint32_t& nl, uint32_t ul, uint32_t n_items, uint32_t ek, uint32_t seg, uint32_t meta,
-                             uint32_t xw, const Rec<RW>& rec, const u32x4_u& ea, const u32x4_u& eb, const uint2& ed) __attribute__((always_inline)) {
+                             uint32_t xw, const Rec<RW>& rec, const u32x4_u (&eq)[NQ], const uint32_t (&et)[NT]) __attribute__((always_inline)) {
 #ifdef MUSC_LANE_DBG
       if (MUSC_LANE_DBG & 32) return;
 #endif
       const bool have = lane < n_items;
       if (!__any(have)) return;
       const int len = (int)REC_LEN(meta);
-      const uint32_t gene = ea.x, jx = ea.y;
-      const uint32_t c[8] = {ea.z, ea.w, eb.x, eb.y, eb.z, eb.w, ed.x, ed.y};
+      // the entry's words: gene, jx, ctx[NW]
+      const uint32_t gene = eq[0].x, jx = eq[0].y;
+      uint32_t c[NW];
+#pragma unroll
+      for (int j = 0; j < NW; j++) {
+        const int wi = j + 2;  // word of the entry
+        c[j] = wi < 4 * NQ ? (wi % 4 == 0 ? eq[wi / 4].x : wi % 4 == 1 ? eq[wi / 4].y : wi % 4 == 2 ? eq[wi / 4].z : eq[wi / 4].w) : et[wi - 4 * NQ];
+      }
       if (W == 2 && direct) {
         // Two windows, a table whose bucket is the key (the usual case): ONE pass with the window per
         // lane -- the read's image for either window, the lane's window's length mask, and the only
@@ -439,35 +481,35 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint32_t sha = 2u * (uint32_t)(CL - q1a), shb = 2u * (uint32_t)(CL - q1b);
         const uint32_t sh = k1 ? shb : sha;
         const int q1 = k1 ? q1b : q1a;
-        uint32_t lm[8];
+        uint32_t lm[NW];
         if (ul != 0xFFFFFFFFu) {
-          const uint32_t (*rows)[8] = mp->lm[__builtin_amdgcn_readfirstlane((int)ul)];
+          const uint32_t (*rows)[CTXW_WORDS] = mp->lm[__builtin_amdgcn_readfirstlane((int)ul)];
 #pragma unroll
-          for (int j = 0; j < 8; j++) lm[j] = k1 ? rows[W - 1][j] : rows[0][j];
+          for (int j = 0; j < NW; j++) lm[j] = k1 ? rows[W - 1][j] : rows[0][j];
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; j++) lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * len - 32 * j);
+          for (int j = 0; j < NW; j++) lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * len - 32 * j);
         }
-        uint32_t wm0[8];  // window 0 of the read, in the coordinates of a comparison through window 1
+        uint32_t wm0[NW];  // window 0 of the read, in the coordinates of a comparison through window 1
         {
           const uint32_t* __restrict__ row = mp->wm[W - 1][0];
 #pragma unroll
-          for (int j = 0; j < 8; j++) wm0[j] = row[j];
+          for (int j = 0; j < NW; j++) wm0[j] = row[j];
         }
         uint32_t z = 0;
         bool ok;
-        if (__any(have && (jx == (uint32_t)q1 || jx == 0u))) ok = have & ctx_fit(jx, c[7] >> 16, q1, ww, len, &z);
-        else ok = have & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[7] >> 16));
+        if (__any(have && (jx == (uint32_t)q1 || jx == 0u))) ok = have & ctx_fit(jx, c[NW - 1] >> 16, q1, ww, len, &z);
+        else ok = have & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[NW - 1] >> 16));
         ncmp += ok ? 1u : 0u;
         uint32_t w = NX_REJECT;
         if (ok) {
-          uint32_t ia[8], ib[8], xm[8];
-          read_image<RW>(rec, sha, ia);
-          read_image<RW>(rec, shb, ib);
+          uint32_t ia[NW], ib[NW], xm[NW];
+          read_image_n<RW, NW>(rec, sha, ia);
+          read_image_n<RW, NW>(rec, shb, ib);
           x_mask(xw, sh, xm);
-          uint32_t d[8], nx = 0, acc0 = 0;
+          uint32_t d[NW], nx = 0, acc0 = 0;
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
+          for (int j = 0; j < NW; j++) {
             const uint32_t df = (k1 ? ib[j] : ia[j]) ^ c[j];
             d[j] = RX ? ((df | (df >> 1)) | xm[j]) & lm[j] : base_diff(df, lm[j]);
             nx = bcnt_add(d[j], nx);
@@ -494,8 +536,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint32_t shk = 2u * (uint32_t)(CL - q1k);
         WinTab tb;
         win_tab(ul, kk, shk, (uint32_t)len, tb);
-        uint32_t img[8], xm[8];
-        read_image<RW>(rec, shk, img);
+        uint32_t img[NW], xm[NW];
+        read_image_n<RW, NW>(rec, shk, img);
         x_mask(xw, shk, xm);
         const uint32_t w2 = score(mine, kk, q1k, img, tb, xm, jx, c, len, REC_BUDGET(meta), REC_VALID(meta), seg);
         if (mine) {
@@ -511,10 +553,11 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     // loads -- the ones past the last item entry 0 of E, which always exists.
     auto entry_fetch = [&]() __attribute__((always_inline)) {
       const uint32_t eix = lane < o_n ? s_oix[wid][lane] : 0u;
-      const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E + (uint64_t)eix);
-      o_a = *reinterpret_cast<const u32x4_u*>(pe);
-      o_b = *reinterpret_cast<const u32x4_u*>(pe + 4);
-      o_d = *reinterpret_cast<const uint2*>(pe + 8);
+      const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + (uint64_t)eix * (NW + 2);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) o_q[q] = *reinterpret_cast<const u32x4_u*>(pe + 4 * q);
+#pragma unroll
+      for (int q = 0; q < NT; q++) o_t[q] = pe[4 * NQ + q];
     };
     // owner tables of the overflow items [c0, c0 + 64) of a wave-tile: item -> (window, read slot) and its
     // place in E; oc / ovf / pre: per lane (= probe) the number of entries beyond the third, where
@@ -552,17 +595,20 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint32_t probe = mine ? (uint32_t)s_own[wid][lane] : 0u;
         const uint32_t eix = mine ? s_oix[wid][lane] : 0u;
         const uint32_t ek = probe >> 6, seg = probe & 63u;
-        const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E + (uint64_t)eix);
-        const u32x4_u ta = *reinterpret_cast<const u32x4_u*>(pe);
-        const u32x4_u tb2 = *reinterpret_cast<const u32x4_u*>(pe + 4);
-        const uint2 td = *reinterpret_cast<const uint2*>(pe + 8);
+        const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + (uint64_t)eix * (NW + 2);
+        u32x4_u tq[NQ];
+        uint32_t tt[NT];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) tq[q] = *reinterpret_cast<const u32x4_u*>(pe + 4 * q);
+#pragma unroll
+        for (int q = 0; q < NT; q++) tt[q] = pe[4 * NQ + q];
         Rec<RW> trec;
         trec.load(rd + (r0 + (uint64_t)wt_prev * WT + seg) * (uint64_t)RW, RW);
         const uint32_t tmeta = s_meta[pp][wid][seg];
         uint32_t txw = 0;
         if constexpr (RX) txw = s_xp[pp][wid][seg];
         wave_lds_sync();  // (the owner tables are rewritten by the next chunk)
-        entry_compare(pp, nlist_prev, ulen_prev, cnt, ek, seg, tmeta, txw, trec, ta, tb2, td);
+        entry_compare(pp, nlist_prev, ulen_prev, cnt, ek, seg, tmeta, txw, trec, tq, tt);
       }
     };
     // phase D for prev: per-read selection and the tuples (the protocol of match_ctx_pass)
@@ -677,7 +723,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     // everything that is left of prev: the pass over its first 64 overflow entries (fetched a window
     // ago, or -- fresh -- right before this call), the rest of them, phase D
     auto finish_prev = [&]() __attribute__((always_inline)) {
-      entry_compare(par ^ 1u, nlist_prev, ulen_prev, o_n, o_k, o_seg, o_meta, o_xw, o_rec, o_a, o_b, o_d);
+      entry_compare(par ^ 1u, nlist_prev, ulen_prev, o_n, o_k, o_seg, o_meta, o_xw, o_rec, o_q, o_t);
       PF(6)
       overflow_rest_prev();
       wave_lds_sync();
@@ -774,7 +820,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint4 h0 = line_l[rb], h1 = line_l[rb ^ 1u];
         const uint32_t cnt = h0.x;
         ncand += cnt;
-        oc[k] = cnt > CTX_INLINE ? cnt - CTX_INLINE : 0u;
+        oc[k] = cnt > (uint32_t)NIN ? cnt - (uint32_t)NIN : 0u;
         ovf[k] = h0.y;
         novf += oc[k];
         PF(2)
@@ -810,35 +856,62 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         wave_lds_sync();
         PF(3)
         // ---- the read's image for this window, then the line's three entries, in this lane
-        uint32_t img[8], xm[8];
+        uint32_t img[NW], xm[NW];
         {
           Rec<RW> rec;
           rec_of(par, lane, rec);
-          read_image<RW>(rec, sh, img);
+          read_image_n<RW, NW>(rec, sh, img);
         }
         x_mask(xw_cur, sh, xm);
-        uint4 ca = line_l[rb ^ 2u], cb = line_l[rb ^ 3u];
-        PF(9)
+        if constexpr (!WIDE) {
+          uint4 ca = line_l[rb ^ 2u], cb = line_l[rb ^ 3u];
+          PF(9)
 #pragma unroll
-        for (int s = 0; s < CTX_INLINE; s++) {
+          for (int s = 0; s < CTX_INLINE; s++) {
 #ifdef MUSC_LANE_DBG
-          const bool live = (uint32_t)s < cnt && !(MUSC_LANE_DBG & 1);
+            const bool live = (uint32_t)s < cnt && !(MUSC_LANE_DBG & 1);
 #else
-          const bool live = (uint32_t)s < cnt;
+            const bool live = (uint32_t)s < cnt;
 #endif
-          if (!__any(live)) break;
-          uint4 na = ca, nb = cb;
-          if (s + 1 < CTX_INLINE) {  // the next entry's context is on its way while this one is compared
-            na = line_l[rb ^ (uint32_t)(2 * s + 4)];
-            nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
+            if (!__any(live)) break;
+            uint4 na = ca, nb = cb;
+            if (s + 1 < CTX_INLINE) {  // the next entry's context is on its way while this one is compared
+              na = line_l[rb ^ (uint32_t)(2 * s + 4)];
+              nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
+            }
+            const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
+            const uint32_t jx = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
+            const uint32_t c[NW] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+            const uint32_t w = score(live, k, q1, img, tb, xm, jx, c, rlen, budget, valid_cur, lane);
+            report_own(w, gene, jx - (uint32_t)q1, wc[k]);
+            ca = na;
+            cb = nb;
           }
-          const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
-          const uint32_t jx = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
-          const uint32_t c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-          const uint32_t w = score(live, k, q1, img, tb, xm, jx, c, rlen, budget, valid_cur, lane);
-          report_own(w, gene, jx - (uint32_t)q1, wc[k]);
-          ca = na;
-          cb = nb;
+        } else {
+          // two entries of fifteen words behind the two header words: the whole line into registers
+          uint32_t L[32];
+          L[0] = h0.x; L[1] = h0.y; L[2] = h0.z; L[3] = h0.w; L[4] = h1.x; L[5] = h1.y; L[6] = h1.z; L[7] = h1.w;
+#pragma unroll
+          for (int q = 2; q < 8; q++) {
+            const uint4 v = line_l[rb ^ (uint32_t)q];
+            L[4 * q] = v.x; L[4 * q + 1] = v.y; L[4 * q + 2] = v.z; L[4 * q + 3] = v.w;
+          }
+          PF(9)
+#pragma unroll
+          for (int s = 0; s < CTXW_INLINE; s++) {
+#ifdef MUSC_LANE_DBG
+            const bool live = (uint32_t)s < cnt && !(MUSC_LANE_DBG & 1);
+#else
+            const bool live = (uint32_t)s < cnt;
+#endif
+            if (!__any(live)) break;
+            const uint32_t gene = L[2 + 15 * s], jx = L[3 + 15 * s];
+            uint32_t c[NW];
+#pragma unroll
+            for (int j = 0; j < NW; j++) c[j] = L[(4 + 15 * s + j) < 32 ? (4 + 15 * s + j) : 0];
+            const uint32_t w = score(live, k, q1, img, tb, xm, jx, c, rlen, budget, valid_cur, lane);
+            report_own(w, gene, jx - (uint32_t)q1, wc[k]);
+          }
         }
         PF(4)
       };

@@ -6,7 +6,7 @@
 #define MATCHT_WAVES 2  // waves per SIMD the register allocator leaves room for (256 VGPRs)
 #endif
 #define MATCHT_WLIST 96  // reported candidates of a wave-tile kept in LDS (cfg3: ~53); more spill to HBM
-template <int RW, int W, bool RX>
+template <int RW, int W, bool RX, bool WIDE>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
@@ -25,12 +25,20 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   (const uint32_t*, uint64_t, uint32_t, const MatchParams*, const uint16_t*, const CtxBucket*, const CtxEntry*, uint4*, \
    uint64_t, uint4*, uint64_t, uint32_t*, uint32_t*, int, uint32_t, uint32_t*, unsigned long long*, const uint4*,   \
    const uint32_t*, const uint32_t*, uint32_t, uint4*, uint64_t, const uint32_t*)
-#define MUSC_LANE_INSTANCES(X, RW) \
-  X template __global__ void k_match_t<RW, 1, false> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 2, false> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 3, false> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 4, false> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 1, true> MUSC_LANE_ARGS;  \
-  X template __global__ void k_match_t<RW, 2, true> MUSC_LANE_ARGS;  \
-  X template __global__ void k_match_t<RW, 3, true> MUSC_LANE_ARGS;  \
-  X template __global__ void k_match_t<RW, 4, true> MUSC_LANE_ARGS;
+#define MUSC_LANE_INSTANCES_WD(X, RW, WD)                                \
+  X template __global__ void k_match_t<RW, 1, false, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 2, false, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 3, false, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 4, false, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 1, true, WD> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 2, true, WD> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 3, true, WD> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 4, true, WD> MUSC_LANE_ARGS;
+// 120-base context buckets: records of 4, 8, 12 words; wide (200 bases): 4 (distant windows), 8, 12, 16.
+// One translation unit per line.
+#define MUSC_LANE_INSTANCES_4(X) MUSC_LANE_INSTANCES_WD(X, 4, false) MUSC_LANE_INSTANCES_WD(X, 4, true)
+#define MUSC_LANE_INSTANCES_8(X) MUSC_LANE_INSTANCES_WD(X, 8, false)
+#define MUSC_LANE_INSTANCES_12(X) MUSC_LANE_INSTANCES_WD(X, 12, false)
+#define MUSC_LANE_INSTANCES_8W(X) MUSC_LANE_INSTANCES_WD(X, 8, true)
+#define MUSC_LANE_INSTANCES_12W(X) MUSC_LANE_INSTANCES_WD(X, 12, true)
+#define MUSC_LANE_INSTANCES_16W(X) MUSC_LANE_INSTANCES_WD(X, 16, true)

@@ -9,4 +9,4 @@
 #include "kernels_match.hpp"
 #include "kernels_match_lane.hpp"
 #include "kernels_match_lane_inst.hpp"
-MUSC_LANE_INSTANCES(, 12)
+MUSC_LANE_INSTANCES_12()

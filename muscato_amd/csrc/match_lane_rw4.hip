@@ -1,4 +1,4 @@
-// k_match_t for records of 4 words: its own translation unit (see kernels_match_lane_inst.hpp)
+// k_match_t for records of 4 words, either bucket width: its own translation unit (see kernels_match_lane_inst.hpp)
 #include <hip/hip_runtime.h>
 #define MUSC_KERNEL static __global__
 #include <type_traits>
@@ -9,4 +9,4 @@
 #include "kernels_match.hpp"
 #include "kernels_match_lane.hpp"
 #include "kernels_match_lane_inst.hpp"
-MUSC_LANE_INSTANCES(, 4)
+MUSC_LANE_INSTANCES_4()

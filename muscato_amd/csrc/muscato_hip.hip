@@ -43,9 +43,12 @@
 #include "kernels_match.hpp"
 #include "kernels_match_lane_inst.hpp"  // k_match_t: declaration only (defined in match_lane_rw*.hip)
 #include "kernels_screen_lane.hpp"
-MUSC_LANE_INSTANCES(extern, 4)
-MUSC_LANE_INSTANCES(extern, 8)
-MUSC_LANE_INSTANCES(extern, 12)
+MUSC_LANE_INSTANCES_4(extern)
+MUSC_LANE_INSTANCES_8(extern)
+MUSC_LANE_INSTANCES_12(extern)
+MUSC_LANE_INSTANCES_8W(extern)
+MUSC_LANE_INSTANCES_12W(extern)
+MUSC_LANE_INSTANCES_16W(extern)
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -162,6 +165,7 @@ struct musc_ctx {
   // whether the reads in hand fit that form under a given mismatch budget (k_xpos_check), cached
   DevBuf<uint32_t> rdx;
   uint64_t rdx_epoch = ~0ull;
+  int rdx_wide = -1;  // the format of rdx: XPos<false> or XPos<true>
   uint64_t xok_epoch = ~0ull;
   double xok_pmatch = -1.0;
   int32_t xok_mmp1 = -1;
@@ -186,6 +190,7 @@ struct musc_ctx {
   uint64_t idx_novf = 0;
   // index kind 1: context buckets (kernels_match.hpp); only one kind is resident at a time
   int idx_kind = 0;         // of the index idx_ww describes: 0 = Bucket table, 1 = CtxBucket table
+  int idx_wide = 0;         // idx_kind 1: the buckets are CtxBucketW (200 bases of context, two inline entries)
   int idx_CL = 0;           // context buckets: bases of left context (the largest window start)
   CtxBucket* ctx_T = nullptr;
   CtxEntry* ctx_E = nullptr;
@@ -890,8 +895,10 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
 // Context buckets for window width ww and CL bases of left context (kernels_match.hpp).
 // Returns 0 and leaves idx_kind == 1 on success; 100 when the table does not fit the device's
 // free memory (the caller then builds the classic index); anything else is an error.
-static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
-  if (c->idx_kind == 1 && c->idx_ww == ww && c->idx_CL == CL && c->ctx_T) return 0;
+static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
+  if (c->idx_kind == 1 && c->idx_ww == ww && c->idx_CL == CL && c->idx_wide == wide && c->ctx_T) return 0;
+  // (ctx_E_cap counts 40-byte CtxEntry; a wide index asks for its 60-byte entries in those units)
+  const uint64_t esz = wide ? sizeof(CtxEntryW) : sizeof(CtxEntry);
   free_index(c);
   c->wide = 0;
   // 4^ww buckets with the key as the bucket (exact) when that is at most twice the database's
@@ -919,7 +926,7 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
     const uint64_t have = (uint64_t)mfree + (c->ctx_T ? c->ctx_T_cap * sizeof(CtxBucket) : 0) +
                           (c->ctx_E ? c->ctx_E_cap * sizeof(CtxEntry) : 0) + c->idx_T_bytes +
                           (c->idx_E ? c->idx_E_cap * sizeof(uint4) : 0);
-    const uint64_t need = (nb + 1) * (sizeof(CtxBucket) + 12) + c->nbases / 3 * sizeof(CtxEntry) + (4ull << 30);
+    const uint64_t need = (nb + 1) * (sizeof(CtxBucket) + 12) + c->nbases / (wide ? 2 : 3) * esz + (4ull << 30);
     if (need > have) return 100;
   }
   // the classic tables go first (one index kind is resident at a time)
@@ -955,11 +962,13 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
   HIPCHK(c, hipMemsetAsync(cursor, 0, (nb + 1) * 4, c->stream));
   const unsigned blocks = (unsigned)std::min<uint64_t>((c->nbases + 255) / 256, 1u << 22);
   if (c->nbases) {
-    hipLaunchKernelGGL(k_index_ctx<false>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
-                       ww, bits, direct, CL, c->ctx_T, (CtxEntry*)nullptr, cursor);
+    // (the counting pass does not look at the entries: one instance serves both layouts)
+    hipLaunchKernelGGL((k_index_ctx<false, false>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+                       ww, bits, direct, CL, c->ctx_T, (void*)nullptr, cursor);
     HIPCHK(c, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_ctx_ovf_count, dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, c->ctx_T, nb, tmp);
+  hipLaunchKernelGGL(k_ctx_ovf_count, dim3(nblk(nb + 1, 256)), dim3(256), 0, c->stream, c->ctx_T, nb,
+                     (uint32_t)(wide ? CTXW_INLINE : CTX_INLINE), tmp);
   HIPCHK(c, hipGetLastError());
   int rc = scan_u64(c, tmp, tmp, nb + 1, stmp);
   if (rc) return rc;
@@ -971,21 +980,26 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (novf >= 0xFFFFFFF0ull) return fail(c, 5, "internal: %llu overflow entries do not fit 32-bit offsets", (unsigned long long)novf);
   c->idx_novf = novf;
-  if (c->ctx_E_cap < novf + 16) {
+  const uint64_t ecap = ((novf + 16) * esz + sizeof(CtxEntry) - 1) / sizeof(CtxEntry);
+  if (c->ctx_E_cap < ecap) {
     if (c->ctx_E) (void)hipFree(c->ctx_E);
     c->ctx_E = nullptr;
     c->ctx_E_cap = 0;
-    if (hipMalloc((void**)&c->ctx_E, (novf + 16) * sizeof(CtxEntry)) != hipSuccess) {
+    if (hipMalloc((void**)&c->ctx_E, ecap * sizeof(CtxEntry)) != hipSuccess) {
       (void)hipGetLastError();
       c->ctx_E = nullptr;
       return 100;
     }
-    c->ctx_E_cap = novf + 16;
+    c->ctx_E_cap = ecap;
   }
   HIPCHK(c, hipEventRecord(e3, c->stream));
   if (c->nbases) {
-    hipLaunchKernelGGL(k_index_ctx<true>, dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
-                       ww, bits, direct, CL, c->ctx_T, c->ctx_E, cursor);
+    if (wide)
+      hipLaunchKernelGGL((k_index_ctx<true, true>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+                         ww, bits, direct, CL, c->ctx_T, (void*)c->ctx_E, cursor);
+    else
+      hipLaunchKernelGGL((k_index_ctx<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+                         ww, bits, direct, CL, c->ctx_T, (void*)c->ctx_E, cursor);
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipEventRecord(e1, c->stream));
@@ -995,6 +1009,7 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL) {
   (void)hipEventElapsedTime(&ms2, e3, e1);
   c->stats.ms_index_build = ms + ms2;
   c->idx_kind = 1;
+  c->idx_wide = wide;
   c->idx_ww = ww;
   c->idx_CL = CL;
   c->idx_bits = bits;
@@ -1014,17 +1029,22 @@ static int match_kind(const musc_ctx* c, int W) {
   return MK_LANE;
 }
 
-// Reads with X fit the context path if every read that holds more than XPOS_MAX of them could not
-// match anyway (that many mismatches exceed its budget int((1 - PMatch) * len)).  One small kernel
-// and a 4-byte readback per (read set, PMatch, MaxMismatch).
-static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
+// Reads with X fit the context path if every read that holds more of them than its xpos word lists
+// (XPos<wide>: four on 120-base buckets, three on wide ones) could not match anyway (that many
+// mismatches exceed its budget int((1 - PMatch) * len)).  One small kernel and a 4-byte readback
+// per (read set, bucket width, PMatch, MaxMismatch).
+static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len, int wide) {
   if (!c->rdm || !c->rd || !c->nreads) return false;
   if (getenv("MUSC_NO_X_CONTEXT")) return false;
-  if (c->rdx_epoch != c->data_epoch) {
+  if (c->rdx_epoch != c->data_epoch || c->rdx_wide != wide) {
     if (ensure(c, c->rdx, c->nreads)) return false;
-    hipLaunchKernelGGL(k_read_xpos, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
+    if (wide)
+      hipLaunchKernelGGL(k_read_xpos<true>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
+    else
+      hipLaunchKernelGGL(k_read_xpos<false>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
     if (hipGetLastError() != hipSuccess) return false;
     c->rdx_epoch = c->data_epoch;
+    c->rdx_wide = wide;
     c->xok_epoch = ~0ull;
   }
   // (the budget table covers the reads in hand whatever length the caller planned the index for)
@@ -1047,7 +1067,7 @@ static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
   if (hipMemcpyAsync(d_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
   if (hipMemsetAsync(c->d_flag, 0, 4, c->stream) != hipSuccess) return false;
   hipLaunchKernelGGL(k_xpos_check, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdx.p, c->nreads, c->rw, d_tab,
-                     max_len, c->d_flag);
+                     max_len, wide ? XPos<true>::MAX : XPos<false>::MAX, c->d_flag);
   if (hipMemcpyAsync(&bad, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
   c->xok = bad == 0;
@@ -1058,35 +1078,44 @@ static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len) {
 }
 
 // Which index a run with these parameters and reads of at most max_len bases uses: context
-// buckets when every read fits their 120 bases of context around each of at most CTX_MAX_W
-// windows, the database holds no X (the context has no mask plane; reads may hold some where
+// buckets when every read fits the context around each of at most CTX_MAX_W windows -- 120 bases
+// (three entries per bucket line) or, where k_match_t runs, 200 bases (two per line: *wide = 1) --
+// the database holds no X (the context has no mask plane; reads may hold some where
 // k_match_t runs, see reads_x_fit) and positions fit 32 bits.
-static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL) {
+static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL, int* wide) {
   if (const char* e = getenv("MUSC_INDEX"))
     if (!strcmp(e, "classic") || !strcmp(e, "lines") || !strcmp(e, "classic64")) return false;  // the two-kernel path
   // (the planes themselves may exist without an X: an all-zero one is made for the side that has
   // none when the other side does, and the database's stays for the context's lifetime)
   if (c->db_has_x) return false;
   if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
-  // reads with X: k_match_t handles them, and only while every read either lists all its X
-  // in its xpos word or has more X than mismatches allowed (reads_x_fit, cached per reads + budget)
-  if (c->reads_have_x && !(match_kind(c, P->n_windows) != MK_QUAD && reads_x_fit(c, P, max_len))) return false;
   if (P->n_windows > CTX_MAX_W) return false;
   int q1min = P->windows[0], q1max = P->windows[0];
   for (int k = 1; k < P->n_windows; k++) {
     q1min = std::min(q1min, P->windows[k]);
     q1max = std::max(q1max, P->windows[k]);
   }
-  if ((int64_t)q1max - q1min + (int64_t)max_len > CTX_BASES) return false;
-  if (q1max > CTX_BASES) return false;
+  const int64_t span = (int64_t)q1max - q1min + (int64_t)max_len;
+  const char* wenv = getenv("MUSC_CONTEXT");  // experiments: "narrow" keeps runs beyond 120 bases on the two-kernel path, "wide" puts every run on wide buckets
+  const bool lane = match_kind(c, P->n_windows) != MK_QUAD;
   *CL = q1max;
+  *wide = 0;
+  if (span > CTX_BASES || q1max > CTX_BASES || (wenv && !strcmp(wenv, "wide") && lane)) {
+    // wide buckets: k_match_t only; records of up to 16 words hold 200-base reads and their length word
+    if (!lane || (wenv && !strcmp(wenv, "narrow"))) return false;
+    if (span > CTXW_BASES || q1max > CTXW_BASES) return false;
+    *wide = 1;
+  }
+  // reads with X: k_match_t handles them, and only while every read either lists all its X
+  // in its xpos word or has more X than mismatches allowed (reads_x_fit, cached per reads + budget)
+  if (c->reads_have_x && !(lane && reads_x_fit(c, P, max_len, *wide))) return false;
   return true;
 }
 
 static int ensure_index(musc_ctx* c, const musc_params* P, uint32_t max_len) {
-  int CL = 0;
-  if (ctx_eligible(c, P, max_len, &CL)) {
-    const int rc = build_index_ctx(c, P->window_width, CL);
+  int CL = 0, wide = 0;
+  if (ctx_eligible(c, P, max_len, &CL, &wide)) {
+    const int rc = build_index_ctx(c, P->window_width, CL, wide);
     if (rc != 100) return rc;
     // (does not fit the free memory: the classic index is a quarter of the size)
   }
@@ -1332,15 +1361,23 @@ static const void* match_fn(const musc_ctx* c, int W) {
   const int kind = match_kind(c, W);
   const bool rx = c->reads_have_x;
   if (kind == MK_LANE) {
-#define MUSC_LANE_FN(WN) (rx ? reinterpret_cast<const void*>(&k_match_t<RW, WN, true>) : reinterpret_cast<const void*>(&k_match_t<RW, WN, false>))
+    // (instances: 120-base buckets for records of 4, 8, 12 words; wide ones for 4 to 16)
+#define MUSC_LANE_FN2(WN, WD) (rx ? reinterpret_cast<const void*>(&k_match_t<RW, WN, true, WD>) : reinterpret_cast<const void*>(&k_match_t<RW, WN, false, WD>))
+#define MUSC_LANE_FN(WN)                                  \
+  if (c->idx_wide) return MUSC_LANE_FN2(WN, true);        \
+  if constexpr (RW <= 12) return MUSC_LANE_FN2(WN, false); \
+  return nullptr;
     switch (W) {
-      case 1: return MUSC_LANE_FN(1);
-      case 2: return MUSC_LANE_FN(2);
-      case 3: return MUSC_LANE_FN(3);
-      default: return MUSC_LANE_FN(4);
+      case 1: MUSC_LANE_FN(1)
+      case 2: MUSC_LANE_FN(2)
+      case 3: MUSC_LANE_FN(3)
+      default: MUSC_LANE_FN(4)
     }
 #undef MUSC_LANE_FN
+#undef MUSC_LANE_FN2
   }
+  if constexpr (RW > 12) return nullptr;
+  else
   return W <= 2 ? reinterpret_cast<const void*>(&k_match<RW, true>) : reinterpret_cast<const void*>(&k_match<RW, false>);
 }
 
@@ -1391,20 +1428,28 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
     uint4* const hp = reinterpret_cast<uint4*>(c->hits.p);
     const uint32_t* const rdx = c->reads_have_x ? (const uint32_t*)c->rdx.p : (const uint32_t*)nullptr;
     if (kind == MK_LANE) {
-#define MUSC_LAUNCH_LANE(WN)                                                                                 \
-      if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, true>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
-      else MUSC_LAUNCH_MATCH((k_match_t<RW, WN, false>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
+#define MUSC_LAUNCH_LANE2(WN, WD)                                                                                 \
+      if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, true, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
+      else MUSC_LAUNCH_MATCH((k_match_t<RW, WN, false, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
+#define MUSC_LAUNCH_LANE(WN)                                      \
+      do {                                                        \
+        if (c->idx_wide) { MUSC_LAUNCH_LANE2(WN, true); }         \
+        else if constexpr (RW <= 12) { MUSC_LAUNCH_LANE2(WN, false); } \
+      } while (0)
       switch (W) {
         case 1: MUSC_LAUNCH_LANE(1); break;
         case 2: MUSC_LAUNCH_LANE(2); break;
         case 3: MUSC_LAUNCH_LANE(3); break;
         default: MUSC_LAUNCH_LANE(4); break;
       }
+#undef MUSC_LAUNCH_LANE2
 #undef MUSC_LAUNCH_LANE
       return;
     }
   }
-  if (W <= 2) MUSC_LAUNCH_MATCH((k_match<RW, true>)); else MUSC_LAUNCH_MATCH((k_match<RW, false>));
+  if constexpr (RW <= 12) {
+    if (W <= 2) MUSC_LAUNCH_MATCH((k_match<RW, true>)); else MUSC_LAUNCH_MATCH((k_match<RW, false>));
+  }
 #undef MUSC_LAUNCH_MATCH
 }
 }  // extern "C++"
@@ -1412,14 +1457,17 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
 static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& pp, int block_mode, uint32_t block_thr_unused,
                           uint64_t max_matches, uint64_t planned_batches, uint64_t* nhits) {
   int rc = 0;
-  if (c->rw != 4 && c->rw != 8 && c->rw != 12) return fail(c, 12, "internal: record stride %d on the context path", c->rw);
+  if (c->rw != 4 && c->rw != 8 && c->rw != 12 && !(c->rw == 16 && c->idx_wide))
+    return fail(c, 12, "internal: record stride %d on the context path", c->rw);
+  if (c->idx_wide && match_kind(c, pp.W) == MK_QUAD) return fail(c, 12, "internal: wide context buckets need k_match_t");
   (void)block_thr_unused;
   // the persistent grid = the workgroups that are resident at once (every wave then sees many
   // wave-tiles and the end-of-kernel atomics stay few); the MaxMatches screening threshold is per
   // workgroup-launch, so it follows the grid
   const unsigned resident = c->rw == 4 ? match_resident<4>(c, pp.W, block_mode)
                             : c->rw == 8 ? match_resident<8>(c, pp.W, block_mode)
-                                         : match_resident<12>(c, pp.W, block_mode);
+                            : c->rw == 12 ? match_resident<12>(c, pp.W, block_mode)
+                                          : match_resident<16>(c, pp.W, block_mode);
   uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * resident), 0x7FFFFFFFull);
   if (block_mode == 1 && block_thr < 2) block_mode = 2;
   if (block_mode == 2 && !c->block_table.p) {
@@ -1528,7 +1576,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       switch (c->rw) {
         case 4: launch_match<4>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
         case 8: launch_match<8>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
-        default: launch_match<12>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
+        case 12: launch_match<12>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
+        default: launch_match<16>(c, r0, n, pp.W, block_mode, block_thr, (unsigned)sgrid, set, pending_tiles); break;
       }
       }
       HIPCHK(c, hipGetLastError());
@@ -1652,8 +1701,9 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     c->stats.ms_select = tm.total(4);
     (void)hipEventElapsedTime(&c->stats.ms_total, ev0, ev1);
     const uint64_t rec_b = (2 * L + 7) / 8;
-    c->stats.match_bytes = c->nreads * rec_b + n_windows * sizeof(CtxBucket) + n_ovf * sizeof(CtxEntry) + 16 * c->stats.n_hits;
-    c->stats.match_bytes_strict = c->nreads * rec_b + n_windows * 8 + n_cand * sizeof(CtxEntry) + 16 * c->stats.n_hits;
+    const uint64_t ent_b = c->idx_wide ? sizeof(CtxEntryW) : sizeof(CtxEntry);
+    c->stats.match_bytes = c->nreads * rec_b + n_windows * sizeof(CtxBucket) + n_ovf * ent_b + 16 * c->stats.n_hits;
+    c->stats.match_bytes_strict = c->nreads * rec_b + n_windows * 8 + n_cand * ent_b + 16 * c->stats.n_hits;
     if (nhits) *nhits = c->nhits;
     c->sized_epoch = c->data_epoch;
     c->sized_params = *P;
@@ -1740,9 +1790,9 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_pp_valid = true;
   }
-  c->stats.index_kind = (uint32_t)c->idx_kind;
+  c->stats.index_kind = c->idx_kind == 1 ? (c->idx_wide ? 2u : 1u) : 0u;
   c->stats.index_bytes = c->idx_kind == 1
-                             ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + (c->idx_novf + 16) * sizeof(CtxEntry)
+                             ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + (c->idx_novf + 16) * (c->idx_wide ? sizeof(CtxEntryW) : sizeof(CtxEntry))
                              : ((1ull << c->idx_bits) + 1) * (c->idx_lines ? sizeof(LineBucket) : sizeof(Bucket)) + (c->idx_novf + 16) * sizeof(uint4);
   if (c->idx_kind == 1)
     return match_ctx_pass(c, P, pp, block_mode, block_thr, max_matches, planned_batches, nhits);

@@ -18,4 +18,7 @@
 #ifndef DEV_RX
 #define DEV_RX false
 #endif
-template __global__ void k_match_t<DEV_RW, DEV_W, DEV_RX> MUSC_LANE_ARGS;
+#ifndef DEV_WIDE
+#define DEV_WIDE false
+#endif
+template __global__ void k_match_t<DEV_RW, DEV_W, DEV_RX, DEV_WIDE> MUSC_LANE_ARGS;

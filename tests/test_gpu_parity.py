@@ -200,9 +200,11 @@ def test_empty_and_degenerate_inputs(eng):
     assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
 
 
-@pytest.mark.parametrize("maxlen", [31, 48, 100, 112, 113, 150, 200, 250, 400])
+@pytest.mark.parametrize("maxlen", [31, 48, 100, 109, 110, 112, 113, 150, 180, 189, 190, 200, 250, 400])
 def test_read_length_strides(eng, maxlen):
-    """Record strides 4/8/12/16 words (compiled) and the runtime-stride kernel."""
+    """Record strides 4/8/12/16 words (compiled) and the runtime-stride kernel; with Windows 0,11 the
+    lengths up to 109 fit 120 bases of context, 110..189 the wide buckets' 200, longer reads take the
+    two-kernel path."""
     rng = random.Random(maxlen)
     targets = [rand_seq(rng, rng.randint(maxlen, 3 * maxlen), b"ACGT") for _ in range(12)]
     targets += [mutate(rng, t, 0.02, b"ACGT") for t in targets[:5]]
@@ -216,6 +218,8 @@ def test_read_length_strides(eng, maxlen):
     reads = sorted(reads)
     c = orc.Config(Windows=[0, 11], WindowWidth=10, PMatch=0.9, MinDinuc=3, MaxReadLength=maxlen, MMTol=2)
     assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
+    if eng.index_mode == "auto":
+        assert eng.stats()["index_kind"] == (1 if maxlen <= 109 else 2 if maxlen <= 189 else 0)
 
 
 def test_wide_windows(eng):
@@ -226,6 +230,47 @@ def test_wide_windows(eng):
     for ww in (17, 20, 31, 32, 33, 40, 64):
         c = orc.Config(Windows=[0, 45], WindowWidth=ww, PMatch=0.95, MaxReadLength=120)
         assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
+
+
+WIDE_CASES = [
+    # windows, ww, read length, pmatch, x in the reads, n_targets, n_reads
+    ((0, 20, 40), 15, 100, 0.97, 0.0, 8000, 100000),   # BASELINE configs[4]'s windows on a database that fits
+    ((0, 20, 40), 11, 100, 0.95, 0.0, 3000, 60000),    # 11-mers: 0.7 entries per key -- many buckets beyond two entries
+    ((0, 20), 15, 150, 0.96, 0.0, 6000, 80000),        # 150-bp reads, records of 12 words
+    ((0, 25), 17, 175, 0.95, 0.0, 4000, 50000),        # 175-bp reads: records of 12 words, hashed table, 200 bases exactly
+    ((0, 20, 40, 60), 12, 140, 0.975, 0.003, 3000, 60000),  # four windows, X in the reads (budget 3 < the 4 X a record lists)
+    ((0, 20), 15, 180, 0.97, 0.0, 3000, 40000),        # records of 16 words
+]
+
+
+@pytest.mark.parametrize("windows,ww,L,pmatch,xrate,nt,nr", WIDE_CASES)
+def test_wide_context_buckets_against_literal_oracle(eng, windows, ww, L, pmatch, xrate, nt, nr):
+    """Runs beyond 120 bases of context (three windows, 150-bp reads ...): on wide context buckets
+    where k_match_t runs (index_kind 2), on the two-kernel path elsewhere -- the same tuples as the
+    reference-shaped C++ oracle, union and best+MMTol selection."""
+    from muscato_amd import sorted_hits
+    reads, targets = synthetic_medium(4000 + ww + L, nt, nr, L=L)
+    if xrate:
+        rng = np.random.default_rng(L)
+        R = np.frombuffer(b"".join(reads), dtype=np.uint8).reshape(-1, L).copy()
+        R[rng.random(R.shape) < xrate] = ord("X")
+        reads = sorted({bytes(r) for r in R})
+    c = orc.Config(Windows=list(windows), WindowWidth=ww, PMatch=pmatch, MinDinuc=3, MaxReadLength=L,
+                   MaxMatches=1000000, MMTol=1)
+    rbuf, roff = literal.concat(reads)
+    gbuf, goff = literal.concat(targets)
+    exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff,
+                                     literal.make_params(c, bloom_size=256_000_000, num_hash=8, nthreads=8))
+    got = gpu_hits(eng, c, reads, targets, False)
+    st = eng.stats()
+    if eng.index_mode == "auto":
+        assert st["index_kind"] == 2
+        if ww <= 12:
+            assert st["n_overflow_entries"] > 1000
+    assert len(got) > nr // 4
+    assert_same(got, exp)
+    best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
+    assert_same(best, as_arr(orc.best_filter([tuple(int(x) for x in r) for r in exp], c.MMTol)))
 
 
 def synthetic_medium(seed, n_targets, n_reads, tlen=1000, L=100, xrate=0.0):
@@ -548,9 +593,9 @@ def test_block_screening_falls_back_to_exact_counters(eng):
 
 def test_index_selection(monkeypatch):
     """Which index a run gets (ensure_index): context buckets + the fused kernel when every read
-    fits 120 bases of context around each of at most four windows and the database holds no X (reads
-    may); the 64-byte buckets and k_screen -> k_confirm otherwise -- with
-    identical tuples either way."""
+    fits 120 bases (index_kind 1) or 200 bases (2: wide buckets) of context around each of at most
+    four windows and the database holds no X (reads may); the window-start buckets and k_screen ->
+    k_confirm otherwise -- with identical tuples either way."""
     from muscato_amd import Config, Engine, sorted_hits
     monkeypatch.delenv("MUSC_INDEX", raising=False)
     monkeypatch.delenv("MUSC_MATCH", raising=False)
@@ -567,18 +612,27 @@ def test_index_selection(monkeypatch):
 
     cases = [
         ("two windows, 100 bp: exactly 120 bases of context", [0, 20], 100, b"ACGT", 1),
-        ("one base too many", [0, 21], 100, b"ACGT", 0),
+        ("one base more: wide context buckets (200 bases, two entries per line)", [0, 21], 100, b"ACGT", 2),
+        ("BASELINE configs[4]'s windows", [0, 20, 40], 100, b"ACGT", 2),
+        ("150-bp reads", [0, 20], 150, b"ACGT", 2),
+        ("exactly 200 bases of context", [0, 20], 180, b"ACGT", 2),
+        ("one base too many for those too", [0, 20], 181, b"ACGT", 0),
+        ("a distant window with short reads", [0, 100], 40, b"ACGT", 2),
         ("four windows, 90 bp", [0, 10, 20, 30], 90, b"ACGT", 1),
         ("five windows", [0, 5, 10, 15, 20], 90, b"ACGT", 0),
+        # (reads with X at PMatch 0.97: a read with more X than its xpos word lists -- four, on wide
+        # buckets three -- then exceeds its budget of three mismatches and takes no part)
         ("reads with X, database without: k_match_t lists a read's X in its xpos word", [0, 20], 100, b"ACGTX", 1),
         ("reads with X, three windows", [0, 10, 20], 100, b"ACGTX", 1),
-        ("long reads", [0, 20], 150, b"ACGT", 0),
+        ("reads with X on wide buckets", [0, 20, 40], 100, b"ACGTX", 2),
+        ("long reads", [0, 20], 250, b"ACGT", 0),
     ]
     with Engine(0) as eng:
         eng.load_targets(targets)
         for what, wins, L, alphabet, kind in cases:
             reads = reads_of(L, alphabet=alphabet)
-            ocfg = orc.Config(Windows=wins, WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=L, MaxMatches=100000, MMTol=1)
+            ocfg = orc.Config(Windows=wins, WindowWidth=12, PMatch=0.97 if b"X" in alphabet else 0.9, MinDinuc=2, MaxReadLength=L,
+                              MaxMatches=100000, MMTol=1)
             eng.load_reads(reads)
             got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
             assert eng.stats()["index_kind"] == kind, what
