@@ -94,6 +94,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   constexpr int NWAVE = TILE / 64;
   // the bucket layout: three inline entries with 8 context words (120 bases), or -- WIDE -- two with 13 (200 bases)
   constexpr int NIN = WIDE ? CTXW_INLINE : CTX_INLINE;
+  // (records of 12 words and more: a shorter candidate list keeps two workgroups within a CU's 160 KB)
+  constexpr uint32_t WLIST = RW >= 12 && MATCHT_WLIST > 64 ? 64u : (uint32_t)MATCHT_WLIST;
   typedef XPos<WIDE> XP;  // how a read's xpos word lists its X
   constexpr int NW = WIDE ? CTXW_WORDS : 8;
   constexpr int NQ = WIDE ? 3 : 2;       // an overflow entry (gene, jx, ctx[NW]) = NQ 16-byte pieces + NT words
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   __shared__ uint32_t s_meta[2][NWAVE][WT];               // length | budget << 17 | valid windows << 24; this wave-tile's and the one before
   __shared__ uint32_t s_xp[RX ? 2 : 1][RX ? NWAVE : 1][RX ? WT : 1];  // reads with X: their xpos words, likewise
   __shared__ uint32_t s_best[2][NWAVE][WT];               // smallest mismatch count the overflow pass reported per read
-  __shared__ uint3 s_list[2][NWAVE][MATCHT_WLIST];        // reported candidates: result word, gene, position
+  __shared__ uint3 s_list[2][NWAVE][WLIST];        // reported candidates: result word, gene, position
   __shared__ uint32_t s_cb[NWAVE][2 * WT];                // phase D: cnt[64], base[64]
   __shared__ uint32_t s_oix[NWAVE][WT];                   // overflow entries: item -> its entry in E
   __shared__ uint8_t s_own[NWAVE][WT];                    //                   item -> window * 64 + read slot
@@ -132,7 +134,9 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   const uint32_t nwt = (n + WT - 1) / WT;
   const uint32_t gw = blockIdx.x * NWAVE + (threadIdx.x >> 6), nw = gridDim.x * NWAVE;
   const uint64_t region = stage_cap / nw, region0 = region * gw;
-  const uint64_t sregion = spill_cap / nw, sregion0 = sregion * gw;
+  // (a wave's spill region has a half per wave-tile parity: the lists of the wave-tile in hand and of the
+  // one before are alive together)
+  const uint64_t sregion = spill_cap / nw / 2, sregion_w = 2 * sregion * gw;
   uint64_t used = 0;      // tuples this wave has staged so far (wave-uniform)
   uint32_t maxspill = 0;  // largest spill a wave-tile of this wave needed
   uint32_t nvalid = 0, ncand = 0, ncmp = 0, novf = 0, nrep = 0;  // per lane: far below 2^32
@@ -447,10 +451,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       nl += (uint32_t)__popcll(vote);
       if (!rep) return;
       atomicMin(&s_best[p][wid][w >> 24], w & 0xFFFFu);
-      if (slot < MATCHT_WLIST) {
+      if (slot < WLIST) {
         s_list[p][wid][slot] = make_uint3(w, gene, pos);
-      } else if (slot - MATCHT_WLIST < sregion) {
-        spill[sregion0 + (slot - MATCHT_WLIST)] = make_uint4(w, gene, pos, 0u);
+      } else if (slot - WLIST < sregion) {
+        spill[sregion_w + p * sregion + (slot - WLIST)] = make_uint4(w, gene, pos, 0u);
       }
     };
     // The comparison pass over overflow entries, a lane per entry: entry (ea | eb | ed), the probe it
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const int wi = j + 2;  // word of the entry
         c[j] = wi < 4 * NQ ? (wi % 4 == 0 ? eq[wi / 4].x : wi % 4 == 1 ? eq[wi / 4].y : wi % 4 == 2 ? eq[wi / 4].z : eq[wi / 4].w) : et[wi - 4 * NQ];
       }
-      if (W == 2 && direct) {
+      if (W == 2 && !WIDE && direct) {
         // Two windows, a table whose bucket is the key (the usual case): ONE pass with the window per
         // lane -- the read's image for either window, the lane's window's length mask, and the only
         // exactness to establish is window 0's for the entries that came through window 1.
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       uint32_t* const best_l = s_best[pp][wid];
       uint32_t* const wcnt_l = s_dyn + (pp * NWAVE + wid) * WT * W;
       const uint32_t nl = nlist_prev;
-      const uint32_t nspill = nl > MATCHT_WLIST ? nl - MATCHT_WLIST : 0u;
+      const uint32_t nspill = nl > WLIST ? nl - WLIST : 0u;
       const bool spill_ok = nspill <= sregion;
       if (nspill > maxspill) maxspill = nspill;
       if (nspill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's spilled candidates have landed
@@ -643,19 +647,19 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       cnt_l[lane] = 0;
       wave_lds_sync();
       auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) __attribute__((always_inline)) -> uint32_t {
-        if (j < MATCHT_WLIST) {
+        if (j < WLIST) {
           const uint3 it = s_list[pp][wid][j];
           *gene = it.y;
           *pos = it.z;
           return it.x;
         }
         // written by other lanes of this wave a moment ago: read past the L1
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(spill + sregion0 + (j - MATCHT_WLIST));
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(spill + sregion_w + pp * sregion + (j - WLIST));
         *gene = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *pos = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
-      const uint32_t nuse = spill_ok ? nl : (nl < MATCHT_WLIST ? nl : MATCHT_WLIST);
+      const uint32_t nuse = spill_ok ? nl : (nl < WLIST ? nl : WLIST);
       // The first two rounds of candidates (a lane each: 128 of them, cfg3 has ~53 per wave-tile) stay
       // in registers from the count to the store: the counting atomic also hands out the tuple's
       // place among its read's; further rounds (spilled lists) are walked twice.
@@ -768,10 +772,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         if (!rep) return;
         const uint32_t v = w & 0xFFFFu;
         best = v < best ? v : best;
-        if (slot < MATCHT_WLIST) {
+        if (slot < WLIST) {
           list_cur[slot] = make_uint3(w, gene, pos);
-        } else if (slot - MATCHT_WLIST < sregion) {
-          spill[sregion0 + (slot - MATCHT_WLIST)] = make_uint4(w, gene, pos, 0u);
+        } else if (slot - WLIST < sregion) {
+          spill[sregion_w + par * sregion + (slot - WLIST)] = make_uint4(w, gene, pos, 0u);
         }
       };
 
@@ -888,29 +892,27 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
             cb = nb;
           }
         } else {
-          // two entries of fifteen words behind the two header words: the whole line into registers
-          uint32_t L[32];
-          L[0] = h0.x; L[1] = h0.y; L[2] = h0.z; L[3] = h0.w; L[4] = h1.x; L[5] = h1.y; L[6] = h1.z; L[7] = h1.w;
-#pragma unroll
-          for (int q = 2; q < 8; q++) {
-            const uint4 v = line_l[rb ^ (uint32_t)q];
-            L[4 * q] = v.x; L[4 * q + 1] = v.y; L[4 * q + 2] = v.z; L[4 * q + 3] = v.w;
-          }
+          // two entries of fifteen words behind the two header words: entry 0 = words 2..16 (h0.zw,
+          // chunks 1-3, chunk 4's first word), entry 1 = words 17..31 (the rest of chunk 4, chunks 5-7)
+          const uint4 m4 = line_l[rb ^ 4u];
           PF(9)
-#pragma unroll
-          for (int s = 0; s < CTXW_INLINE; s++) {
-#ifdef MUSC_LANE_DBG
-            const bool live = (uint32_t)s < cnt && !(MUSC_LANE_DBG & 1);
-#else
-            const bool live = (uint32_t)s < cnt;
-#endif
-            if (!__any(live)) break;
-            const uint32_t gene = L[2 + 15 * s], jx = L[3 + 15 * s];
-            uint32_t c[NW];
-#pragma unroll
-            for (int j = 0; j < NW; j++) c[j] = L[(4 + 15 * s + j) < 32 ? (4 + 15 * s + j) : 0];
-            const uint32_t w = score(live, k, q1, img, tb, xm, jx, c, rlen, budget, valid_cur, lane);
-            report_own(w, gene, jx - (uint32_t)q1, wc[k]);
+          {
+            const bool live = cnt > 0u;
+            if (__any(live)) {
+              const uint4 c2 = line_l[rb ^ 2u], c3 = line_l[rb ^ 3u];
+              const uint32_t c[NW] = {h1.x, h1.y, h1.z, h1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, m4.x};
+              const uint32_t w = score(live, k, q1, img, tb, xm, h0.w, c, rlen, budget, valid_cur, lane);
+              report_own(w, h0.z, h0.w - (uint32_t)q1, wc[k]);
+            }
+          }
+          {
+            const bool live = cnt > 1u;
+            if (__any(live)) {
+              const uint4 c5 = line_l[rb ^ 5u], c6 = line_l[rb ^ 6u], c7 = line_l[rb ^ 7u];
+              const uint32_t c[NW] = {m4.w, c5.x, c5.y, c5.z, c5.w, c6.x, c6.y, c6.z, c6.w, c7.x, c7.y, c7.z, c7.w};
+              const uint32_t w = score(live, k, q1, img, tb, xm, m4.z, c, rlen, budget, valid_cur, lane);
+              report_own(w, m4.y, m4.z - (uint32_t)q1, wc[k]);
+            }
           }
         }
         PF(4)

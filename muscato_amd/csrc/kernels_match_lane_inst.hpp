@@ -5,7 +5,9 @@
 #ifndef MATCHT_WAVES
 #define MATCHT_WAVES 2  // waves per SIMD the register allocator leaves room for (256 VGPRs)
 #endif
+#ifndef MATCHT_WLIST
 #define MATCHT_WLIST 96  // reported candidates of a wave-tile kept in LDS (cfg3: ~53); more spill to HBM
+#endif
 template <int RW, int W, bool RX, bool WIDE>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,

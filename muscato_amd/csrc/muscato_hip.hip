@@ -1404,7 +1404,12 @@ static unsigned match_resident(musc_ctx* c, int W, int block_mode) {
     }
   }
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
-  return (unsigned)per_cu * (unsigned)ncu;
+  unsigned resident = (unsigned)per_cu * (unsigned)ncu;
+  if (const char* g = getenv("MUSC_DEBUG_GRID")) {  // tests: a small grid makes every wave walk many wave-tiles of a small input
+    const int v = atoi(g);
+    if (v >= 1 && (unsigned)v < resident) resident = (unsigned)v;
+  }
+  return resident;
 }
 
 // set: which staging buffers the launch fills (0: stage / tcount2, 1: stage_b / tcount2_b);
@@ -1557,7 +1562,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         if ((rc = ensure(c, c->tcount2, (uint64_t)ntiles + 1))) return rc;
         if ((rc = ensure(c, c->tpre, (uint64_t)ntiles + 1))) return rc;
         if ((rc = ensure(c, c->stage, std::max<uint64_t>(2ull * n, swaves * 64)))) return rc;
-        if ((rc = ensure(c, c->spill, swaves * 16))) return rc;
+        if ((rc = ensure(c, c->spill, swaves * 32))) return rc;
         if (fuse && ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
                      (rc = ensure(c, c->tpre_b, c->tpre.cap))))
           return rc;
@@ -1592,7 +1597,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       if (!sized) {
         HIPCHK(c, hipMemcpyAsync(&c->h_pinned[0], c->counters, 16 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint64_t need_stage = c->h_pinned[8 + 7] * swaves, need_spill = c->h_pinned[8 + 5] * swaves;
+        // (k_match_t keeps a spill region per wave and wave-tile parity)
+        const uint64_t need_stage = c->h_pinned[8 + 7] * swaves, need_spill = 2 * c->h_pinned[8 + 5] * swaves;
         if (need_stage > (1ull << 31)) {  // u32 tuple offsets within a batch: retry with half the reads
           if (n == 1) return fail(c, 6, "one read has %llu tuples (> 2^31)", (unsigned long long)c->h_pinned[8 + 7]);
           bsz = n / 2;

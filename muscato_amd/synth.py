@@ -52,6 +52,12 @@ WORKLOADS = {
     # per-GPU shard of cfg4 (200M reads / 8 GPUs) against the same replicated 1M-target DB
     "cfg4shard": Workload("cfg4 shard: 25M reads x 1M targets", 1_000_000, 1000, 25_000_000, 100, (0, 20), 15,
                           0.97, 0, 5),
+    # runs beyond 120 bases of context (wide context buckets): cfg3's database with configs[4]'s three
+    # windows, and with 150-bp reads
+    "cfg3w3": Workload("cfg3 with Windows 0,20,40: 50M reads x 1M targets", 1_000_000, 1000, 50_000_000, 100, (0, 20, 40), 15,
+                       0.97, 0, 5),
+    "cfg3r150": Workload("cfg3 with 150-bp reads: 25M reads x 1M targets", 1_000_000, 1000, 25_000_000, 150, (0, 20), 15,
+                         0.97, 0, 5),
     "tiny": Workload("tiny: 20k reads x 2k targets", 2_000, 1000, 20_000, 100, (0, 20), 15, 0.97, 0, 5),
     # per-GPU shard of cfg5: 200M reads / 8 GPUs against 5M targets + reverse complements (10 Gbp),
     # three windows, MMTol=3 ("exhaustive multi-map")

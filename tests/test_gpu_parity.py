@@ -743,6 +743,19 @@ def test_batches_of_heavy_tiles_move_their_tuples_in_the_next_launch(monkeypatch
                     assert st["index_kind"] == 1 and st["n_batches"] == -(-len(reads) // int(batch))
                     assert (np.diff(raw[:, 0].astype(np.int64)) >= 0).all(), "the hit list is not read-major"
                     assert_same(sorted_hits(raw), exp)
+    # one batch on a grid of three workgroups: every wave walks some forty wave-tiles in a row, each
+    # with a candidate list that spills past LDS -- the lists of the wave-tile in hand and of the one
+    # before it are alive together and must not share spill space
+    monkeypatch.delenv("MUSC_BATCH_READS", raising=False)
+    monkeypatch.setenv("MUSC_DEBUG_GRID", "3")
+    with Engine(0) as eng:
+        eng.load_targets(targets)
+        eng.load_reads(reads)
+        for mode, exp in ((False, exp_all), (True, exp_best)):
+            for rep in range(2):
+                raw = eng.match(to_cfg(ocfg), apply_mmtol=mode)
+                assert eng.stats()["index_kind"] == 1 and eng.stats()["n_batches"] == 1
+                assert_same(sorted_hits(raw), exp)
 
 
 def _x_in_reads_only(seed, n_targets, n_reads, xrate, heavy):
