@@ -514,7 +514,28 @@ def main() -> int:
                 times.append(((t_dn - t1) * 1e3, (t_up - t1) * 1e3, (t_m - t_up) * 1e3, (t_dn - t_m) * 1e3))
                 assert n == n0, "survey-scope pass found %d tuples, the resident pass %d" % (n, n0)
             best = min(times)
+            # the same three steps one after the other (the upload finished before the match starts): what
+            # the pipelined form hides.  (A copy + kernel trace would show the same on a time line;
+            # rocprofv3 --memory-copy-trace dies at exit on this image, profiles/README.md.)
+            serial = []
+            for rep in range(2):
+                t1 = time.perf_counter()
+                eng.load_reads_packed32_ptr(h_packed.data_ptr(), 0, 0, wl.read_len, n_loaded, async_upload=False)
+                t_up = time.perf_counter()
+                n = match()
+                t_m = time.perf_counter()
+                if n and compact:
+                    eng.hits_to_compact(h_words.data_ptr(), nmax, h_counts.data_ptr(), n_loaded + 8, False, cbits)
+                elif n:
+                    eng.hits_to(h_hits.data_ptr(), n, False)
+                t_dn = time.perf_counter()
+                serial.append(((t_dn - t1) * 1e3, (t_up - t1) * 1e3, (t_m - t_up) * 1e3, (t_dn - t_m) * 1e3))
+                assert n == n0
+            sbest = min(serial)
             legs["survey_scope"] = {
+                "serial": {"ms_per_pass": sbest[0], "ms_upload_then_pack": sbest[1], "ms_match": sbest[2], "ms_tuples_to_host": sbest[3],
+                           "what": "the same steps without overlap (blocking upload, then the match, then the download); best of 2"},
+                "ms_hidden_by_overlap": sbest[0] - best[0],
                 "ms_per_pass": best[0], "reads_per_s": wl.n_raw_reads / (best[0] / 1e3),
                 "ms_queue_upload": best[1], "ms_match_overlapping_upload": best[2], "ms_tuples_to_host": best[3],
                 "all_reps_ms": [round(x[0], 3) for x in times],
@@ -579,10 +600,12 @@ def main() -> int:
         scr_bytes = (st["n_reads"] * rec_b + st["n_read_windows"] * 8 + st["n_candidates"] * 16 + st["n_descriptors"] * 12) / sl
         ms_scr = acc["ms_screen"] / max(acc["screen_launches"], 1)
         scr_ach = (scr_bytes / 1e9) / (ms_scr / 1e3) if ms_scr > 0 else 0.0
+        lines = st["index_kind"] == 3  # line buckets: a probe is one 128-byte line (16 B header + 7 entries), walked by k_screen_t
+        sname = "k_screen_t" if lines and os.environ.get("MUSC_SCREEN") != "wg" else "k_screen"
         screen_roof = {
-            "kernel": "k_screen", "bound": "hbm", "achieved": scr_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": sname, "bound": "hbm", "achieved": scr_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": scr_ach / HBM_PEAK_GBS, "frac_of_measured_copy_peak": scr_ach / HBM_COPY_GBS,
-            "traffic": measured_traffic(tkey, "k_screen") if not args.reads else None,
+            "traffic": measured_traffic(tkey, sname) if not args.reads else None,
             "traffic_source": TRAFFIC_FILE + " (recorded PMC passes; not measured by this run)",
             "algorithmic_bytes": "%d B per read record + 8 B bucket header per probe + 16 B per index entry walked + "
                                  "12 B per descriptor written" % rec_b,
@@ -646,7 +669,8 @@ def main() -> int:
             },
             "index": {"kind": "context buckets (128 B: 3 x 120 bases, fused k_match_t)" if kind == 1
                       else "wide context buckets (128 B: 2 x 200 bases, fused k_match_t)" if kind == 2
-                      else "window-start buckets (k_screen -> k_confirm)",
+                      else "line buckets (128 B: header + 7 window starts; k_screen_t -> k_confirm)" if kind == 3
+                      else "64-byte window-start buckets (k_screen -> k_confirm)",
                       "bytes": st["index_bytes"]},
             "roofline": dominant, "roofline_confirm": confirm_roof, "roofline_screen": screen_roof,
             "per_step": {

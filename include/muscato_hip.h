@@ -111,10 +111,11 @@ typedef struct {
                              * when two windows of the read found it (then it is two pairs);
                              * 0 with context buckets (no descriptors exist)               */
   /* ---- since ABI version 2 */
-  uint32_t index_kind;      /* index the pass ran on: 0 = window-start buckets + target gather
-                             * (k_screen -> k_confirm), 1 = context buckets, 120 bases
-                             * (k_match_t or k_match), 2 = wide context buckets, 200 bases
-                             * (k_match_t)                                                  */
+  uint32_t index_kind;      /* index the pass ran on: 0 = 64-byte window-start buckets + target
+                             * gather (k_screen -> k_confirm), 3 = the same on 128-byte line
+                             * buckets (dense databases; k_screen_t -> k_confirm), 1 = context
+                             * buckets, 120 bases (k_match_t or k_match), 2 = wide context
+                             * buckets, 200 bases (k_match_t)                                */
   uint32_t match_launches;  /* launches of that kernel (index_kind 1)                       */
   uint64_t n_overflow_entries; /* index entries beyond a bucket's inline ones that were walked */
   uint64_t match_bytes;     /* algorithmic bytes of those launches: record (ceil(2L/8) B)

@@ -1796,7 +1796,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_pp_valid = true;
   }
-  c->stats.index_kind = c->idx_kind == 1 ? (c->idx_wide ? 2u : 1u) : 0u;
+  c->stats.index_kind = c->idx_kind == 1 ? (c->idx_wide ? 2u : 1u) : (c->idx_lines ? 3u : 0u);
   c->stats.index_bytes = c->idx_kind == 1
                              ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + (c->idx_novf + 16) * (c->idx_wide ? sizeof(CtxEntryW) : sizeof(CtxEntry))
                              : ((1ull << c->idx_bits) + 1) * (c->idx_lines ? sizeof(LineBucket) : sizeof(Bucket)) + (c->idx_novf + 16) * sizeof(uint4);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The committed bench lines of a round (run from the repo root through gpurun):
-#   profiles/bench_lines.sh r02
-tag=${1:-r02}
+#   profiles/bench_lines.sh r03
+tag=${1:-r03}
 o=gpurun_out
 python bench.py --steps 20 --warmup 5 > $o/${tag}_cfg3_bench.json 2> $o/${tag}_cfg3_bench.err || echo "cfg3 FAILED"
 python bench.py --steps 20 --warmup 5 --index classic --no-cpu-baseline --no-survey-scope > $o/${tag}_cfg3_classic_bench.json 2>/dev/null || echo "cfg3 classic FAILED"
@@ -14,10 +14,15 @@ MUSC_BENCH_BACKEND=gloo MUSC_BENCH_DEVICE=0 MUSC_INDEX=classic timeout -k 10 400
 # one rank in an RCCL group: the N>1 code with device buffers (the transfers have no peer)
 MUSC_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --workload cfg4shard --steps 10 --warmup 2 > $o/${tag}_rccl1_rehearsal.json 2> $o/${tag}_rccl1_rehearsal.err || { echo "rccl1 FAILED"; tail -5 $o/${tag}_rccl1_rehearsal.err; }
 MUSC_GRAPH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_cfg3_graph_bench.json 2>/dev/null || echo "cfg3 graph FAILED"
-# reads with X (0.1 % of the read bases; the database stays X-free): context buckets (k_match_d, RX) and the two-kernel path
+# reads with X (0.1 % of the read bases; the database stays X-free): context buckets (k_match_t, RX) and the two-kernel path
 python bench.py --xrate 0.001 --x-reads-only --no-cpu-baseline --no-survey-scope --steps 10 > $o/${tag}_cfg3_xreads_bench.json 2>/dev/null || echo "cfg3 xreads FAILED"
 MUSC_NO_X_CONTEXT=1 python bench.py --xrate 0.001 --x-reads-only --no-cpu-baseline --no-survey-scope --steps 10 > $o/${tag}_cfg3_xreads_classic_bench.json 2>/dev/null || echo "cfg3 xreads classic FAILED"
-for f in cfg3 cfg3_classic cfg2 cfg4shard cfg5shard n2_rehearsal; do
+# runs beyond 120 bases of context: wide context buckets, and the two-kernel path they took before
+for wl in cfg3w3 cfg3r150; do
+  python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_${wl}_bench.json 2>/dev/null || echo "$wl FAILED"
+  MUSC_CONTEXT=narrow python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_${wl}_classic_bench.json 2>/dev/null || echo "$wl classic FAILED"
+done
+for f in cfg3 cfg3_classic cfg2 cfg4shard cfg5shard cfg3w3 cfg3w3_classic cfg3r150 cfg3r150_classic n2_rehearsal; do
   python - <<PY
 import json
 try:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect a round's profile evidence on the GPU box (run from the repo root through gpurun):
-#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard
+#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150
 # Per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --steps 5` (kernel
 # statistics + the JSON line of that very run), then separate --pmc passes (never combined with a
 # trace; one counter group per pass; the program directly after `--`) for HBM traffic.  cfg3 also gets
@@ -9,7 +9,7 @@
 # gpurun_out/prof_<tag>/; the summaries land in gpurun_out/<tag>_* -- copy those into profiles/.
 set -o pipefail
 tag=${1:-r03}; shift
-wls=${@:-cfg3 cfg2 cfg4shard cfg5shard}
+wls=${@:-cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -35,7 +35,7 @@ for wl in $wls; do
     done
     mkdir -p $out/pmcs_${wl}_$kind; mv $out/pmc_${wl}_${kind}_[0-9] $out/pmcs_${wl}_$kind/ 2>/dev/null
     key=$wl; [ "$kind" = "classic" ] && key=${wl}_classic
-    python3 profiles/traffic_from_pmc.py $out/pmcs_${wl}_$kind $key k_match_t k_match k_screen k_confirm k_compact_w k_compact > $out/traffic_$key.json
+    python3 profiles/traffic_from_pmc.py $out/pmcs_${wl}_$kind $key k_match_t k_match k_screen_t k_screen k_confirm k_compact_w k_compact > $out/traffic_$key.json
     rm -rf $out/pmcs_${wl}_$kind $out/stats_${wl}_$kind/*/*.db 2>/dev/null
   done
 done

@@ -22,7 +22,7 @@ from muscato_amd import Config, Engine, sorted_hits
 # MUSC_FUZZ_READS_X=1: X in the reads only (an X-free database: with at most two windows and reads
 # of at most 112 bases those runs take k_match_d's RX path whenever every read's X fit its xpos word)
 READS_X_ONLY = bool(os.environ.get("MUSC_FUZZ_READS_X"))
-KINDS = {0: 0, 1: 0}
+KINDS = {0: 0, 1: 0, 2: 0, 3: 0}
 
 
 def case(seed):

@@ -44,9 +44,9 @@ def _hamming_ok(T_flat, TL, R, h, L, chunk=2_000_000):
 @pytest.mark.parametrize("name,index", [("cfg3", "auto"), ("cfg3", "quad"), ("cfg3", "classic"), ("cfg5shard", "auto")])
 def test_baseline_config_at_full_size(name, index, monkeypatch):
     """index "auto": what the library picks -- context buckets + the fused k_match for cfg3 (two
-    windows, 100-bp reads: 120 bases of context), the 64-byte-bucket index + k_screen -> k_confirm
-    for the cfg5 shard (three windows do not fit the context; 10 Gbp would not fit the table);
-    "classic" forces the latter for cfg3 as well."""
+    windows, 100-bp reads: 120 bases of context), line buckets + k_screen_t -> k_confirm
+    for the cfg5 shard (10 Gbp: positions beyond 32 bits, and the context table would not fit);
+    "classic" forces the two-kernel path (on 64-byte buckets: a sparse database) for cfg3 as well."""
     import torch
     monkeypatch.delenv("MUSC_MATCH", raising=False)
     if index == "quad":  # context buckets with k_match instead of k_match_t
@@ -56,7 +56,7 @@ def test_baseline_config_at_full_size(name, index, monkeypatch):
         monkeypatch.setenv("MUSC_INDEX", "classic")
     else:
         monkeypatch.delenv("MUSC_INDEX", raising=False)
-    want_kind = 1 if name == "cfg3" and index in ("auto", "quad") else 0
+    want_kind = 1 if name == "cfg3" and index in ("auto", "quad") else 3 if name == "cfg5shard" else 0  # cfg5: line buckets
     from muscato_amd import Config, Engine, sorted_hits, synth
     from oracle import literal
     from oracle import muscato_oracle as orc

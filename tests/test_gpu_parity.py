@@ -491,8 +491,8 @@ def test_low_complexity_stress(eng):
                                      literal.make_params(c, bloom_size=64_000_000, num_hash=6, nthreads=8))
     got = gpu_hits(eng, c, reads, targets, False)
     st = eng.stats()
-    assert st["index_kind"] == (0 if eng.index_mode in ("classic", "lines") else 1)
-    assert (st["n_descriptors"] if st["index_kind"] == 0 else st["n_pairs"]) > 1_000_000 and len(got) > 500_000
+    assert st["index_kind"] == {"classic": 0, "lines": 3}.get(eng.index_mode, 1)
+    assert (st["n_descriptors"] if st["index_kind"] in (0, 3) else st["n_pairs"]) > 1_000_000 and len(got) > 500_000
     assert_same(got, exp)
     assert st["n_overflow_blocks"] == 0
     best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
@@ -788,7 +788,7 @@ def test_reads_with_x_against_an_x_free_database(eng, pmatch, ww, windows, fits)
                                      literal.make_params(c, bloom_size=128_000_000, num_hash=8, nthreads=8))
     got = gpu_hits(eng, c, reads, targets, False)
     st = eng.stats()
-    assert st["index_kind"] == (1 if fits and eng.index_mode == "auto" else 0)
+    assert st["index_kind"] == (1 if fits and eng.index_mode == "auto" else 3 if eng.index_mode == "lines" else 0)
     assert len(got) > 8000
     assert_same(got, exp)
     best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
