@@ -46,6 +46,13 @@
 //
 // LDS per workgroup of four waves: 4 x 16.2 KB + the MaxMatches sketch = 73 KB: two workgroups per CU
 // (registers: ~230 of the 256 two waves per SIMD may use).
+//
+// WIDE (template flag): the same kernel on CtxBucketW lines -- two inline entries of 200 context bases
+// (13 words) instead of three of 120 (8 words), 60-byte overflow entries -- for runs whose reads do not
+// fit 120 bases around every window (Windows 0,20,40 at 100 bp; 150-bp reads).  Everything that is
+// "eight words" above is NW words here; a read's X are listed as three 8-bit positions (XPos<true>).
+// Records of 12 words and more keep 64 reported candidates in LDS instead of 96 so that two
+// workgroups still fit a CU; records of 16 words (reads of 177-200 bases) run one workgroup per CU.
 #pragma once
 #include "kernels_match_lane_inst.hpp"
 
