@@ -55,6 +55,9 @@
 // workgroups still fit a CU; records of 16 words (reads of 177-200 bases) run one workgroup per CU.
 #pragma once
 #include "kernels_match_lane_inst.hpp"
+#if defined(MUSC_LANE_DBG) && !defined(MUSC_LANE_DBG_SLOTS)
+#define MUSC_LANE_DBG_SLOTS 3
+#endif
 
 // The read's image for a window: the record shifted left by sh bits (wave-uniform), NW words -- read_image
 // of kernels_match.hpp for either context width
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
 #pragma unroll
           for (int s = 0; s < CTX_INLINE; s++) {
 #ifdef MUSC_LANE_DBG
-            const bool live = (uint32_t)s < cnt && !(MUSC_LANE_DBG & 1);
+            const bool live = (uint32_t)s < cnt && !(MUSC_LANE_DBG & 1) && s < MUSC_LANE_DBG_SLOTS;  // (timing experiments: wrong tuples)
 #else
             const bool live = (uint32_t)s < cnt;
 #endif

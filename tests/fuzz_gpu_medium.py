@@ -5,7 +5,8 @@ WindowWidth 6-20 (direct and hashed index), PMatch 0.9-1, MinDinuc 0-6, MMTol 0-
 accepted tuples and the best+MMTol selection.  Round 1: seeds 0..85000, no mismatch (28 min on
 one MI355X); round 2 (both index kinds, as each configuration selects): seeds 0..56000 with k_match,
 0..80000 with k_match_d where a configuration has at most two windows, and 0..20000 with
-MUSC_FUZZ_READS_X=1 (X in the reads only): no mismatch."""
+MUSC_FUZZ_READS_X=1 (X in the reads only): no mismatch; round 3 (k_match_t, wide and line buckets): seeds
+0..22000 and 0..9000 with MUSC_FUZZ_READS_X=1, no mismatch, all four index kinds used."""
 import os
 import sys
 import time
