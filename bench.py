@@ -39,6 +39,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # same guide: 6.29 TB/s measured float4 copy
+RANDOM_LINES_PER_S = 46.5e9  # measured on this part: random whole 128-byte lines, a quad of lanes per line, nothing else in the kernel (profiles/ub_random_lines.hip)
+
+
+def line_rate(roof):
+    """The kernels of this path fetch random 128-byte lines: how many per second the recorded PMC
+    traffic of the dominant kernel amounts to, against the part's measured random-line rate."""
+    if roof and roof.get("traffic") and roof.get("avg_launch_ms"):
+        lps = roof["traffic"] / 128.0 / (roof["avg_launch_ms"] / 1e3)
+        roof["lines_per_s_from_traffic"] = lps
+        roof["frac_of_measured_random_line_rate"] = lps / RANDOM_LINES_PER_S
+    return roof
 TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
@@ -649,6 +660,8 @@ def main() -> int:
                 "avg_launch_ms": ms_m, "launches_per_step": st["match_launches"], "not_billed": fused_note,
             }
             dominant, confirm_roof, screen_roof = match_roof, None, None
+        for r_ in (dominant, confirm_roof, screen_roof):
+            line_rate(r_)
         res = {
             "metric": "reads/sec (100 bp, multi-map) at 1/2/4/8 MI355X; confirm-kernel HBM GB/s vs peak",  # BASELINE.json's wording: value = reads/sec, the kernels are under "roofline*"
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
