@@ -37,7 +37,7 @@ struct __attribute__((aligned(128))) CtxBucket {
 };
 static_assert(sizeof(CtxBucket) == 128, "a context bucket is one cache line");
 
-struct CtxEntry {  // overflow entry, 40 bytes (8-byte aligned)
+struct CtxEntry {  // overflow entry, 40 bytes; three per 128-byte line of E (ctx_entry_word)
   uint32_t gene, jx;
   uint32_t ctx[8];
 };
@@ -62,6 +62,18 @@ struct __attribute__((aligned(128))) CtxBucketW {
   CtxEntryW e[CTXW_INLINE];
 };
 static_assert(sizeof(CtxBucketW) == 128, "a wide context bucket is one cache line");
+
+// Where overflow entry i sits in E, in 32-bit words: an entry never straddles a 128-byte line -- three
+// 40-byte entries (wide: two of 60 bytes) per line, the last 8 bytes of a line unused.  A 40-byte
+// entry at 40 * i would cross a line boundary three times in ten and cost two requests.
+template <bool WIDE>
+__host__ __device__ inline uint64_t ctx_entry_word(uint32_t i) {
+  if (WIDE) return (uint64_t)(i >> 1) * 32u + (i & 1u) * 15u;
+  const uint32_t q = i / 3u;
+  return (uint64_t)q * 32u + (i - 3u * q) * 10u;
+}
+// bytes of E for n overflow entries
+inline uint64_t ctx_entries_bytes(uint64_t n, bool wide) { return (wide ? (n + 1) / 2 : (n + 2) / 3) * 128ull; }
 
 // 64 bits of the stream from a possibly negative bit offset (zeros before the stream start)
 DEV uint64_t ext64s(const uint32_t* __restrict__ w, long long bo) {
@@ -123,14 +135,13 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
         ent.gene = gene;
         ent.jx = (uint32_t)jx;
         ctx_words<CTXW_WORDS>(db2, g, e, CL, ent.ctx);
-        CtxEntryW* p = slot < CTXW_INLINE ? &TW[b].e[slot] : reinterpret_cast<CtxEntryW*>(Ev) + ((uint64_t)TW[b].ovf + (slot - CTXW_INLINE));
-        uint32_t* pw = reinterpret_cast<uint32_t*>(p);
+        uint32_t* pw = slot < CTXW_INLINE ? reinterpret_cast<uint32_t*>(&TW[b].e[slot])
+                                          : reinterpret_cast<uint32_t*>(Ev) + ctx_entry_word<true>(TW[b].ovf + (slot - CTXW_INLINE));
         pw[0] = ent.gene;
         pw[1] = ent.jx;
 #pragma unroll
         for (int i = 0; i < CTXW_WORDS; i++) pw[2 + i] = ent.ctx[i];
       } else {
-        CtxEntry* const E = reinterpret_cast<CtxEntry*>(Ev);
         uint32_t c[8];
         ctx_words<8>(db2, g, e, CL, c);
         if (slot < CTX_INLINE) {
@@ -140,11 +151,11 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
           dst[0] = make_uint4(c[0], c[1], c[2], c[3]);
           dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
         } else {
-          CtxEntry* p = E + ((uint64_t)T[b].ovf + (slot - CTX_INLINE));
-          p->gene = gene;
-          p->jx = (uint32_t)jx;
+          uint32_t* p = reinterpret_cast<uint32_t*>(Ev) + ctx_entry_word<false>(T[b].ovf + (slot - CTX_INLINE));
+          p[0] = gene;
+          p[1] = (uint32_t)jx;
 #pragma unroll
-          for (int i = 0; i < 8; i++) p->ctx[i] = c[i];
+          for (int i = 0; i < 8; i++) p[2 + i] = c[i];
         }
       }
     }
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
             k = probe >> 6;
             seg = probe & 63u;
             const uint32_t* __restrict__ pe =
-                reinterpret_cast<const uint32_t*>(E + ((uint64_t)ovf_l[probe] + e));
+                reinterpret_cast<const uint32_t*>(E) + ctx_entry_word<false>(ovf_l[probe] + e);
             const uint2 hd = *reinterpret_cast<const uint2*>(pe);
             const u32x4_u x = *reinterpret_cast<const u32x4_u*>(pe + 2);
             const u32x4_u y = *reinterpret_cast<const u32x4_u*>(pe + 6);

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     // loads -- the ones past the last item entry 0 of E, which always exists.
     auto entry_fetch = [&]() __attribute__((always_inline)) {
       const uint32_t eix = lane < o_n ? s_oix[wid][lane] : 0u;
-      const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + (uint64_t)eix * (NW + 2);
+      const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + ctx_entry_word<WIDE>(eix);
 #pragma unroll
       for (int q = 0; q < NQ; q++) o_q[q] = *reinterpret_cast<const u32x4_u*>(pe + 4 * q);
 #pragma unroll
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint32_t probe = mine ? (uint32_t)s_own[wid][lane] : 0u;
         const uint32_t eix = mine ? s_oix[wid][lane] : 0u;
         const uint32_t ek = probe >> 6, seg = probe & 63u;
-        const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + (uint64_t)eix * (NW + 2);
+        const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + ctx_entry_word<WIDE>(eix);
         u32x4_u tq[NQ];
         uint32_t tt[NT];
 #pragma unroll

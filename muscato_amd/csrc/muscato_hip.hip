@@ -980,7 +980,7 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (novf >= 0xFFFFFFF0ull) return fail(c, 5, "internal: %llu overflow entries do not fit 32-bit offsets", (unsigned long long)novf);
   c->idx_novf = novf;
-  const uint64_t ecap = ((novf + 16) * esz + sizeof(CtxEntry) - 1) / sizeof(CtxEntry);
+  const uint64_t ecap = (ctx_entries_bytes(novf + 16, wide) + sizeof(CtxEntry) - 1) / sizeof(CtxEntry);  // (entries sit line-aligned: ctx_entry_word)
   if (c->ctx_E_cap < ecap) {
     if (c->ctx_E) (void)hipFree(c->ctx_E);
     c->ctx_E = nullptr;
@@ -1798,7 +1798,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   }
   c->stats.index_kind = c->idx_kind == 1 ? (c->idx_wide ? 2u : 1u) : (c->idx_lines ? 3u : 0u);
   c->stats.index_bytes = c->idx_kind == 1
-                             ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + (c->idx_novf + 16) * (c->idx_wide ? sizeof(CtxEntryW) : sizeof(CtxEntry))
+                             ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + ctx_entries_bytes(c->idx_novf + 16, c->idx_wide)
                              : ((1ull << c->idx_bits) + 1) * (c->idx_lines ? sizeof(LineBucket) : sizeof(Bucket)) + (c->idx_novf + 16) * sizeof(uint4);
   if (c->idx_kind == 1)
     return match_ctx_pass(c, P, pp, block_mode, block_thr, max_matches, planned_batches, nhits);
