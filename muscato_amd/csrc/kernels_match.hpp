@@ -27,6 +27,7 @@
 #define CTX_BASES 120
 #define CTX_INLINE 3
 #define CTX_MAX_W 4
+#define CTX_XFLAG 0x80000000u  // in an entry's jx word: the context overlaps an X of the database
 
 struct __attribute__((aligned(128))) CtxBucket {
   uint32_t count;
@@ -97,8 +98,23 @@ DEV void ctx_words(const uint32_t* __restrict__ db2, uint64_t g, uint64_t e, int
   c[NW - 1] = (c[NW - 1] & 0xFFFFu) | ((uint32_t)(rem > 65535 ? 65535 : rem) << 16);
 }
 
+// bits [2 g, 2 (g + n)) of the mask plane hold an X
+DEV bool plane_any_x(const uint32_t* __restrict__ dbm2, uint64_t g, uint32_t n) {
+  uint64_t bo = 2 * g;
+  int left = 2 * (int)n;
+  while (left > 0) {
+    const int take = left < 64 ? left : 64;
+    if (ext64(dbm2, bo) & lowmask64(take)) return true;
+    bo += 64;
+    left -= 64;
+  }
+  return false;
+}
+
+// dbm2 / dbx: the database's mask plane and its X-block bitmap, or null for a database without X
 template <bool SCATTER, bool WIDE>
-__global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ db2,
+__global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2,
+                                                   const uint32_t* __restrict__ dbx,
                                                    const uint64_t* __restrict__ seq_off, uint32_t nseq,
                                                    uint64_t nbases, int ww, int bits, int direct, int CL,
                                                    CtxBucket* __restrict__ T, void* __restrict__ Ev,
@@ -124,6 +140,15 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
     const uint64_t s = seq_off[gene], e = seq_off[gene + 1];
     const uint64_t jx = g - s;
     if (jx + (uint64_t)ww > e - s) continue;  // window would cross the target end
+    uint32_t xflag = 0;
+    if (dbx) {
+      // a window with an X has no key here; an entry whose context span (clipped to the database)
+      // touches a block with an X is flagged -- conservative, the kernel then consults the plane
+      if (db_span_has_x(dbx, g, (uint32_t)ww) && plane_any_x(dbm2, g, (uint32_t)ww)) continue;
+      const long long lo = (long long)g - (long long)CL, hi = lo + (WIDE ? CTXW_BASES : CTX_BASES);
+      const uint64_t c0 = lo > 0 ? (uint64_t)lo : 0ull, c1 = (uint64_t)hi < nbases ? (uint64_t)hi : nbases;
+      if (db_span_has_x(dbx, c0, (uint32_t)(c1 - c0))) xflag = CTX_XFLAG;
+    }
     const uint32_t b = bucket_of(db2, nullptr, 2 * g, ww, bits, direct);
     if (!SCATTER) {
       atomicAdd(&T[b].count, 1u);
@@ -133,7 +158,7 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
         CtxBucketW* const TW = reinterpret_cast<CtxBucketW*>(T);
         CtxEntryW ent;
         ent.gene = gene;
-        ent.jx = (uint32_t)jx;
+        ent.jx = (uint32_t)jx | xflag;
         ctx_words<CTXW_WORDS>(db2, g, e, CL, ent.ctx);
         uint32_t* pw = slot < CTXW_INLINE ? reinterpret_cast<uint32_t*>(&TW[b].e[slot])
                                           : reinterpret_cast<uint32_t*>(Ev) + ctx_entry_word<true>(TW[b].ovf + (slot - CTXW_INLINE));
@@ -146,14 +171,14 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
         ctx_words<8>(db2, g, e, CL, c);
         if (slot < CTX_INLINE) {
           T[b].gene[slot] = gene;
-          T[b].jx[slot] = (uint32_t)jx;
+          T[b].jx[slot] = (uint32_t)jx | xflag;
           uint4* dst = reinterpret_cast<uint4*>(T[b].ctx[slot]);
           dst[0] = make_uint4(c[0], c[1], c[2], c[3]);
           dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
         } else {
           uint32_t* p = reinterpret_cast<uint32_t*>(Ev) + ctx_entry_word<false>(T[b].ovf + (slot - CTX_INLINE));
           p[0] = gene;
-          p[1] = (uint32_t)jx;
+          p[1] = (uint32_t)jx | xflag;
 #pragma unroll
           for (int i = 0; i < 8; i++) p[2 + i] = c[i];
         }
@@ -188,6 +213,9 @@ struct MatchParams {
   uint32_t q1zero_mask;
   int32_t dbg;  // experiments only (MUSC_DEBUG_MATCH): 1 skip the comparisons, 2 skip the bucket loads, 4 skip phase C
   int32_t win[CTX_MAX_W];
+  // a database with X (k_match_t<.., XM = 2>): where a target starts and the mask plane, read for flagged entries only
+  const uint64_t* seq_off;
+  const uint32_t* dbm2;
   // Scalar mask tables, filled by the host (match_tables): a comparison through window k works in
   // the coordinates of the context stream, where the read sits at bits [sh_k, sh_k + 2 len), sh_k =
   // 2 * (CL - win[k]).  Word j of
@@ -940,6 +968,23 @@ MUSC_KERNEL void k_xpos_check(const uint32_t* __restrict__ rd, const uint32_t* _
   if (cnt == 15u || cnt <= budget) atomicOr(bad, 1u);
 }
 
+// The same question when the DATABASE holds X as well (k_match_t<.., XM = 2>): there an X of a read can
+// match an X of a target, so a read with more X than its word lists cannot be written off, and a read
+// window that holds an X could equal a database window that does (not indexed): *bad = 1 if some read
+// has an X beyond its word's list or inside one of the run's windows.
+struct XWins { int32_t n, ww, q1[CTX_MAX_W]; };
+template <bool WIDE>
+__global__ void k_xpos_check_db(const uint32_t* __restrict__ xpos, uint64_t nreads, XWins wn, uint32_t* __restrict__ bad) {
+  typedef XPos<WIDE> XP;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  const uint32_t w = xpos[i], cnt = XPOS_CNT(w);
+  if (!cnt) return;
+  bool b = cnt > XP::MAX;
+  for (uint32_t q = 0; q < XP::MAX && q < cnt; q++)
+    for (int k = 0; k < wn.n; k++) b |= XP::at(w, q) - (uint32_t)wn.q1[k] < (uint32_t)wn.ww;
+  if (b) atomicOr(bad, 1u);
+}
 
 // k_compact_w -- hits[counters[2] + tpre[wt] ...] = the wave-tile's staged tuples (tpre = scan of
 // tcount2), a wave per wave-tile: plain 16-byte copies, contiguous on both sides.

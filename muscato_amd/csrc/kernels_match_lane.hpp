@@ -85,7 +85,8 @@ DEV void read_image_n(const Rec<RW>& rec, uint32_t sh, uint32_t (&img)[NW]) {
 #undef MUSC_IMG_W
 }
 
-template <int RW, int W, bool RX, bool WIDE>
+
+template <int RW, int W, int XM, bool WIDE>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
@@ -101,6 +102,9 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
                                                                 uint4* __restrict__ hits, uint64_t hits_cap,
                                                                 const uint32_t* __restrict__ rdx) {
   static_assert(W >= 1 && W <= CTX_MAX_W, "context buckets serve at most CTX_MAX_W windows");
+  // XM: 0 = neither side holds an X; 1 = reads may (their xpos words, rdx); 2 = the database does (flagged
+  // entries consult its mask plane) and reads may
+  constexpr bool RX = XM != 0, DBX = XM == 2;
   constexpr int NWAVE = TILE / 64;
   // the bucket layout: three inline entries with 8 context words (120 bases), or -- WIDE -- two with 13 (200 bases)
   constexpr int NIN = WIDE ? CTXW_INLINE : CTX_INLINE;
@@ -325,8 +329,37 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   // from the same mismatch mask, which windows of the read match the target exactly here (the pair is
   // reported through the first of them only).  slot = the read's slot in its wave-tile.  Returns the
   // pair's result word (NX_REJECT, or nmiss | NX_DUP | NX_ACC0 | window << 20 | slot << 24).
-  auto score = [&](bool live, int k, int q1, const uint32_t (&img)[NW], const WinTab& tb, const uint32_t (&xm)[NW], uint32_t jx,
-                   const uint32_t (&c)[NW], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
+  // a database with X: the X of the target span an entry's context covers, in the context's coordinates
+  // (one bit per base, as xm) -- read from the mask plane for the lanes whose entry is flagged, zero for
+  // the others.  A rare path: its loads wait on the spot.
+  auto target_xmask = [&](bool want, uint32_t gene, uint32_t jx, uint32_t (&tm)[NW]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NW; j++) tm[j] = 0;
+    if constexpr (DBX) {
+      if (__any(want)) {
+        if (want) {
+          const uint64_t* __restrict__ so = mp->seq_off;
+          const uint32_t* __restrict__ dm = mp->dbm2;
+          const long long bo = 2 * ((long long)(so[gene] + jx) - (long long)CL);
+#pragma unroll
+          for (int i = 0; i < (NW + 1) / 2; i++) {
+            const uint64_t v = ext64s(dm, bo + 64 * i);
+            tm[2 * i] = (uint32_t)v & 0x55555555u;
+            if (2 * i + 1 < NW) tm[2 * i + 1] = (uint32_t)(v >> 32) & 0x55555555u;
+          }
+        }
+      }
+    }
+  };
+  // the mismatch bits of one context word: x = image ^ context, xm / tm = the X of the read / of the target
+  // (X == X is a match, X against a base a mismatch), lm = the bases that take part
+  auto diff_word = [&](uint32_t x, uint32_t xmj, uint32_t tmj, uint32_t lmj) __attribute__((always_inline)) -> uint32_t {
+    if constexpr (DBX) return ((((x | (x >> 1)) & ~(xmj & tmj)) | (xmj ^ tmj))) & lmj;
+    else if constexpr (RX) return ((x | (x >> 1)) | xmj) & lmj;
+    else return base_diff(x, lmj);
+  };
+  auto score = [&](bool live, int k, int q1, const uint32_t (&img)[NW], const WinTab& tb, const uint32_t (&xm)[NW], uint32_t gene, uint32_t jx,
+                   bool xf, const uint32_t (&c)[NW], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
     // a placement must start inside the target (p = jx - q1 >= 0) and end inside it; the pos-0 rules
     // (ctx_fit) are evaluated only when some lane of the wave is at p == 0 or at target position 0
     uint32_t z = 0;
@@ -335,13 +368,14 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     else ok = live & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[NW - 1] >> 16));
     ncmp += ok ? 1u : 0u;
     uint32_t w = NX_REJECT;
+    uint32_t tm[NW];
+    target_xmask(ok && xf, gene, jx, tm);
     if (ok) {
       uint32_t d[NW], nx = 0;
 #pragma unroll
       for (int j = 0; j < NW; j++) {
         // (lm has no bit in the high half of the last word, where the context keeps the distance to the target end)
-        const uint32_t x = img[j] ^ c[j];
-        d[j] = RX ? ((x | (x >> 1)) | xm[j]) & tb.lm[j] : base_diff(x, tb.lm[j]);
+        d[j] = diff_word(img[j] ^ c[j], xm[j], tm[j], tb.lm[j]);
         nx = bcnt_add(d[j], nx);
       }
       uint32_t exact = valid & (z ? ~q1zero : 0xFFFFFFFFu);
@@ -479,7 +513,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       if (!__any(have)) return;
       const int len = (int)REC_LEN(meta);
       // the entry's words: gene, jx, ctx[NW]
-      const uint32_t gene = eq[0].x, jx = eq[0].y;
+      const uint32_t gene = eq[0].x, jx = DBX ? eq[0].y & ~CTX_XFLAG : eq[0].y;
+      const bool xf = DBX && (eq[0].y & CTX_XFLAG) != 0;
       uint32_t c[NW];
 #pragma unroll
       for (int j = 0; j < NW; j++) {
@@ -516,6 +551,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         else ok = have & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[NW - 1] >> 16));
         ncmp += ok ? 1u : 0u;
         uint32_t w = NX_REJECT;
+        uint32_t tm[NW];
+        target_xmask(ok && xf, gene, jx, tm);
         if (ok) {
           uint32_t ia[NW], ib[NW], xm[NW];
           read_image_n<RW, NW>(rec, sha, ia);
@@ -524,8 +561,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
           uint32_t d[NW], nx = 0, acc0 = 0;
 #pragma unroll
           for (int j = 0; j < NW; j++) {
-            const uint32_t df = (k1 ? ib[j] : ia[j]) ^ c[j];
-            d[j] = RX ? ((df | (df >> 1)) | xm[j]) & lm[j] : base_diff(df, lm[j]);
+            d[j] = diff_word((k1 ? ib[j] : ia[j]) ^ c[j], xm[j], tm[j], lm[j]);
             nx = bcnt_add(d[j], nx);
             acc0 = and_or_s(d[j], wm0[j], acc0);
           }
@@ -553,7 +589,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         uint32_t img[NW], xm[NW];
         read_image_n<RW, NW>(rec, shk, img);
         x_mask(xw, shk, xm);
-        const uint32_t w2 = score(mine, kk, q1k, img, tb, xm, jx, c, len, REC_BUDGET(meta), REC_VALID(meta), seg);
+        const uint32_t w2 = score(mine, kk, q1k, img, tb, xm, gene, jx, xf, c, len, REC_BUDGET(meta), REC_VALID(meta), seg);
         if (mine) {
           w = w2;
           q1 = q1k;
@@ -894,9 +930,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
               nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
             }
             const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
-            const uint32_t jx = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
+            const uint32_t jxr = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
+            const uint32_t jx = DBX ? jxr & ~CTX_XFLAG : jxr;
             const uint32_t c[NW] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-            const uint32_t w = score(live, k, q1, img, tb, xm, jx, c, rlen, budget, valid_cur, lane);
+            const uint32_t w = score(live, k, q1, img, tb, xm, gene, jx, DBX && (jxr & CTX_XFLAG) != 0, c, rlen, budget, valid_cur, lane);
             report_own(w, gene, jx - (uint32_t)q1, wc[k]);
             ca = na;
             cb = nb;
@@ -911,8 +948,9 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
             if (__any(live)) {
               const uint4 c2 = line_l[rb ^ 2u], c3 = line_l[rb ^ 3u];
               const uint32_t c[NW] = {h1.x, h1.y, h1.z, h1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, m4.x};
-              const uint32_t w = score(live, k, q1, img, tb, xm, h0.w, c, rlen, budget, valid_cur, lane);
-              report_own(w, h0.z, h0.w - (uint32_t)q1, wc[k]);
+              const uint32_t jx = DBX ? h0.w & ~CTX_XFLAG : h0.w;
+              const uint32_t w = score(live, k, q1, img, tb, xm, h0.z, jx, DBX && (h0.w & CTX_XFLAG) != 0, c, rlen, budget, valid_cur, lane);
+              report_own(w, h0.z, jx - (uint32_t)q1, wc[k]);
             }
           }
           {
@@ -920,8 +958,9 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
             if (__any(live)) {
               const uint4 c5 = line_l[rb ^ 5u], c6 = line_l[rb ^ 6u], c7 = line_l[rb ^ 7u];
               const uint32_t c[NW] = {m4.w, c5.x, c5.y, c5.z, c5.w, c6.x, c6.y, c6.z, c6.w, c7.x, c7.y, c7.z, c7.w};
-              const uint32_t w = score(live, k, q1, img, tb, xm, m4.z, c, rlen, budget, valid_cur, lane);
-              report_own(w, m4.y, m4.z - (uint32_t)q1, wc[k]);
+              const uint32_t jx = DBX ? m4.z & ~CTX_XFLAG : m4.z;
+              const uint32_t w = score(live, k, q1, img, tb, xm, m4.y, jx, DBX && (m4.z & CTX_XFLAG) != 0, c, rlen, budget, valid_cur, lane);
+              report_own(w, m4.y, jx - (uint32_t)q1, wc[k]);
             }
           }
         }

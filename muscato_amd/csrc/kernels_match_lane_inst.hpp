@@ -8,7 +8,7 @@
 #ifndef MATCHT_WLIST
 #define MATCHT_WLIST 96  // reported candidates of a wave-tile kept in LDS (cfg3: ~53); more spill to HBM
 #endif
-template <int RW, int W, bool RX, bool WIDE>
+template <int RW, int W, int XM, bool WIDE>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
@@ -28,14 +28,18 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
    uint64_t, uint4*, uint64_t, uint32_t*, uint32_t*, int, uint32_t, uint32_t*, unsigned long long*, const uint4*,   \
    const uint32_t*, const uint32_t*, uint32_t, uint4*, uint64_t, const uint32_t*)
 #define MUSC_LANE_INSTANCES_WD(X, RW, WD)                                \
-  X template __global__ void k_match_t<RW, 1, false, WD> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 2, false, WD> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 3, false, WD> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 4, false, WD> MUSC_LANE_ARGS; \
-  X template __global__ void k_match_t<RW, 1, true, WD> MUSC_LANE_ARGS;  \
-  X template __global__ void k_match_t<RW, 2, true, WD> MUSC_LANE_ARGS;  \
-  X template __global__ void k_match_t<RW, 3, true, WD> MUSC_LANE_ARGS;  \
-  X template __global__ void k_match_t<RW, 4, true, WD> MUSC_LANE_ARGS;
+  X template __global__ void k_match_t<RW, 1, 0, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 2, 0, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 3, 0, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 4, 0, WD> MUSC_LANE_ARGS; \
+  X template __global__ void k_match_t<RW, 1, 1, WD> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 2, 1, WD> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 3, 1, WD> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 4, 1, WD> MUSC_LANE_ARGS;  \
+  X template __global__ void k_match_t<RW, 1, 2, WD> MUSC_LANE_ARGS;     \
+  X template __global__ void k_match_t<RW, 2, 2, WD> MUSC_LANE_ARGS;     \
+  X template __global__ void k_match_t<RW, 3, 2, WD> MUSC_LANE_ARGS;     \
+  X template __global__ void k_match_t<RW, 4, 2, WD> MUSC_LANE_ARGS;
 // 120-base context buckets: records of 4, 8, 12 words; wide (200 bases): 4 (distant windows), 8, 12, 16.
 // One translation unit per line.
 #define MUSC_LANE_INSTANCES_4(X) MUSC_LANE_INSTANCES_WD(X, 4, false) MUSC_LANE_INSTANCES_WD(X, 4, true)

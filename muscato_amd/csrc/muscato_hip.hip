@@ -171,6 +171,12 @@ struct musc_ctx {
   int32_t xok_mmp1 = -1;
   bool xok = false;
   uint32_t* dbx = nullptr;   // with dbm2: one bit per 64-base block that holds an X
+  uint64_t max_tlen = 0;     // longest target (context buckets flag an entry in bit 31 of its position)
+  // a database with X on context buckets (k_match_t<.., XM = 2>): whether the reads in hand keep their X
+  // out of the run's windows and within their xpos words (k_xpos_check_db), cached per read set and windows
+  uint64_t xokdb_epoch = ~0ull;
+  int32_t xokdb_key[CTX_MAX_W + 3] = {0};
+  bool xokdb = false;
   uint64_t* seq_off = nullptr;
   uint32_t nseq = 0;
   uint64_t nbases = 0;
@@ -675,7 +681,14 @@ static int db_xblocks(musc_ctx* c) {
 static int db_finish(musc_ctx* c) {
   uint32_t hasx = 0;
   HIPCHK(c, hipMemcpyAsync(&hasx, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+  // the longest target
+  unsigned long long tl = 0;
+  HIPCHK(c, hipMemsetAsync(c->counters + 4, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_max_len, dim3(std::min(nblk(c->nseq, 256), MAX_GRID)), dim3(256), 0, c->stream, c->seq_off, (uint64_t)c->nseq, c->counters + 4);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(&tl, c->counters + 4, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->max_tlen = tl;
   c->db_has_x = hasx != 0;
   if (!hasx) {
     (void)hipFree(c->dbm2);
@@ -961,9 +974,12 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
   HIPCHK(c, hipMemsetAsync(c->ctx_T, 0, (nb + 1) * sizeof(CtxBucket), c->stream));
   HIPCHK(c, hipMemsetAsync(cursor, 0, (nb + 1) * 4, c->stream));
   const unsigned blocks = (unsigned)std::min<uint64_t>((c->nbases + 255) / 256, 1u << 22);
+  // a database with X: its windows with an X stay out, entries whose context touches one are flagged
+  const uint32_t* const xm2 = c->db_has_x ? c->dbm2 : nullptr;
+  const uint32_t* const xbl = c->db_has_x ? c->dbx : nullptr;
   if (c->nbases) {
     // (the counting pass does not look at the entries: one instance serves both layouts)
-    hipLaunchKernelGGL((k_index_ctx<false, false>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+    hipLaunchKernelGGL((k_index_ctx<false, false>), dim3(blocks), dim3(256), 0, c->stream, c->db2, xm2, xbl, c->seq_off, c->nseq, c->nbases,
                        ww, bits, direct, CL, c->ctx_T, (void*)nullptr, cursor);
     HIPCHK(c, hipGetLastError());
   }
@@ -995,10 +1011,10 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
   HIPCHK(c, hipEventRecord(e3, c->stream));
   if (c->nbases) {
     if (wide)
-      hipLaunchKernelGGL((k_index_ctx<true, true>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+      hipLaunchKernelGGL((k_index_ctx<true, true>), dim3(blocks), dim3(256), 0, c->stream, c->db2, xm2, xbl, c->seq_off, c->nseq, c->nbases,
                          ww, bits, direct, CL, c->ctx_T, (void*)c->ctx_E, cursor);
     else
-      hipLaunchKernelGGL((k_index_ctx<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->db2, c->seq_off, c->nseq, c->nbases,
+      hipLaunchKernelGGL((k_index_ctx<true, false>), dim3(blocks), dim3(256), 0, c->stream, c->db2, xm2, xbl, c->seq_off, c->nseq, c->nbases,
                          ww, bits, direct, CL, c->ctx_T, (void*)c->ctx_E, cursor);
     HIPCHK(c, hipGetLastError());
   }
@@ -1029,6 +1045,22 @@ static int match_kind(const musc_ctx* c, int W) {
   return MK_LANE;
 }
 
+// The xpos words of the reads in hand, in the format of the bucket width
+static bool reads_xpos(musc_ctx* c, int wide) {
+  if (c->rdx_epoch == c->data_epoch && c->rdx_wide == wide) return true;
+  if (ensure(c, c->rdx, c->nreads)) return false;
+  if (wide)
+    hipLaunchKernelGGL(k_read_xpos<true>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
+  else
+    hipLaunchKernelGGL(k_read_xpos<false>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
+  if (hipGetLastError() != hipSuccess) return false;
+  c->rdx_epoch = c->data_epoch;
+  c->rdx_wide = wide;
+  c->xok_epoch = ~0ull;
+  c->xokdb_epoch = ~0ull;
+  return true;
+}
+
 // Reads with X fit the context path if every read that holds more of them than its xpos word lists
 // (XPos<wide>: four on 120-base buckets, three on wide ones) could not match anyway (that many
 // mismatches exceed its budget int((1 - PMatch) * len)).  One small kernel and a 4-byte readback
@@ -1036,17 +1068,7 @@ static int match_kind(const musc_ctx* c, int W) {
 static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len, int wide) {
   if (!c->rdm || !c->rd || !c->nreads) return false;
   if (getenv("MUSC_NO_X_CONTEXT")) return false;
-  if (c->rdx_epoch != c->data_epoch || c->rdx_wide != wide) {
-    if (ensure(c, c->rdx, c->nreads)) return false;
-    if (wide)
-      hipLaunchKernelGGL(k_read_xpos<true>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
-    else
-      hipLaunchKernelGGL(k_read_xpos<false>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rd, c->rdm, c->nreads, c->rw, c->rdx.p);
-    if (hipGetLastError() != hipSuccess) return false;
-    c->rdx_epoch = c->data_epoch;
-    c->rdx_wide = wide;
-    c->xok_epoch = ~0ull;
-  }
+  if (!reads_xpos(c, wide)) return false;
   // (the budget table covers the reads in hand whatever length the caller planned the index for)
   max_len = std::max(max_len, c->max_len);
   if (c->xok_epoch == c->data_epoch && c->xok_pmatch == P->pmatch && c->xok_mmp1 == P->max_mismatch_p1) return c->xok;
@@ -1077,6 +1099,30 @@ static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len, int
   return c->xok;
 }
 
+// Reads with X against a DATABASE with X fit the context path if every read lists all its X in its
+// xpos word and none of them falls into one of the run's windows (k_xpos_check_db).
+static bool reads_x_fit_db(musc_ctx* c, const musc_params* P, int wide) {
+  if (!c->rdm || !c->rd || !c->nreads) return false;
+  if (!reads_xpos(c, wide)) return false;
+  int32_t key[CTX_MAX_W + 3] = {P->n_windows, P->window_width, wide};
+  XWins wn;
+  memset(&wn, 0, sizeof wn);
+  wn.n = P->n_windows;
+  wn.ww = P->window_width;
+  for (int k = 0; k < P->n_windows && k < CTX_MAX_W; k++) key[3 + k] = wn.q1[k] = P->windows[k];
+  if (c->xokdb_epoch == c->data_epoch && memcmp(key, c->xokdb_key, sizeof key) == 0) return c->xokdb;
+  uint32_t bad = 1;
+  if (hipMemsetAsync(c->d_flag, 0, 4, c->stream) != hipSuccess) return false;
+  if (wide) hipLaunchKernelGGL(k_xpos_check_db<true>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rdx.p, c->nreads, wn, c->d_flag);
+  else hipLaunchKernelGGL(k_xpos_check_db<false>, dim3(nblk(c->nreads, 256)), dim3(256), 0, c->stream, c->rdx.p, c->nreads, wn, c->d_flag);
+  if (hipMemcpyAsync(&bad, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+  c->xokdb = bad == 0;
+  c->xokdb_epoch = c->data_epoch;
+  memcpy(c->xokdb_key, key, sizeof key);
+  return c->xokdb;
+}
+
 // Which index a run with these parameters and reads of at most max_len bases uses: context
 // buckets when every read fits the context around each of at most CTX_MAX_W windows -- 120 bases
 // (three entries per bucket line) or, where k_match_t runs, 200 bases (two per line: *wide = 1) --
@@ -1087,7 +1133,10 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
     if (!strcmp(e, "classic") || !strcmp(e, "lines") || !strcmp(e, "classic64")) return false;  // the two-kernel path
   // (the planes themselves may exist without an X: an all-zero one is made for the side that has
   // none when the other side does, and the database's stays for the context's lifetime)
-  if (c->db_has_x) return false;
+  const bool lane = match_kind(c, P->n_windows) != MK_QUAD;
+  // a database with X: k_match_t only (entries whose context touches an X are flagged in bit 31 of
+  // their position and compared through the mask plane)
+  if (c->db_has_x && (!lane || c->max_tlen >= 0x80000000ull || getenv("MUSC_NO_X_CONTEXT"))) return false;
   if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
   if (P->n_windows > CTX_MAX_W) return false;
   int q1min = P->windows[0], q1max = P->windows[0];
@@ -1097,7 +1146,6 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
   }
   const int64_t span = (int64_t)q1max - q1min + (int64_t)max_len;
   const char* wenv = getenv("MUSC_CONTEXT");  // experiments: "narrow" keeps runs beyond 120 bases on the two-kernel path, "wide" puts every run on wide buckets
-  const bool lane = match_kind(c, P->n_windows) != MK_QUAD;
   *CL = q1max;
   *wide = 0;
   if (span > CTX_BASES || q1max > CTX_BASES || (wenv && !strcmp(wenv, "wide") && lane)) {
@@ -1108,7 +1156,7 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
   }
   // reads with X: k_match_t handles them, and only while every read either lists all its X
   // in its xpos word or has more X than mismatches allowed (reads_x_fit, cached per reads + budget)
-  if (c->reads_have_x && !(lane && reads_x_fit(c, P, max_len, *wide))) return false;
+  if (c->reads_have_x && !(lane && (c->db_has_x ? reads_x_fit_db(c, P, *wide) : reads_x_fit(c, P, max_len, *wide)))) return false;
   return true;
 }
 
@@ -1362,7 +1410,7 @@ static const void* match_fn(const musc_ctx* c, int W) {
   const bool rx = c->reads_have_x;
   if (kind == MK_LANE) {
     // (instances: 120-base buckets for records of 4, 8, 12 words; wide ones for 4 to 16)
-#define MUSC_LANE_FN2(WN, WD) (rx ? reinterpret_cast<const void*>(&k_match_t<RW, WN, true, WD>) : reinterpret_cast<const void*>(&k_match_t<RW, WN, false, WD>))
+#define MUSC_LANE_FN2(WN, WD) (c->db_has_x ? reinterpret_cast<const void*>(&k_match_t<RW, WN, 2, WD>) : rx ? reinterpret_cast<const void*>(&k_match_t<RW, WN, 1, WD>) : reinterpret_cast<const void*>(&k_match_t<RW, WN, 0, WD>))
 #define MUSC_LANE_FN(WN)                                  \
   if (c->idx_wide) return MUSC_LANE_FN2(WN, true);        \
   if constexpr (RW <= 12) return MUSC_LANE_FN2(WN, false); \
@@ -1434,8 +1482,9 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
     const uint32_t* const rdx = c->reads_have_x ? (const uint32_t*)c->rdx.p : (const uint32_t*)nullptr;
     if (kind == MK_LANE) {
 #define MUSC_LAUNCH_LANE2(WN, WD)                                                                                 \
-      if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, true, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
-      else MUSC_LAUNCH_MATCH((k_match_t<RW, WN, false, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
+      if (c->db_has_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 2, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
+      else if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 1, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
+      else MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 0, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
 #define MUSC_LAUNCH_LANE(WN)                                      \
       do {                                                        \
         if (c->idx_wide) { MUSC_LAUNCH_LANE2(WN, true); }         \
@@ -1484,6 +1533,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     mp.W = pp.W; mp.ww = pp.ww; mp.min_dinuc = pp.min_dinuc; mp.bits = pp.bits; mp.direct = pp.direct;
     mp.mmtol = pp.mmtol; mp.apply_mmtol = pp.apply_mmtol; mp.max_len = pp.max_len; mp.CL = c->idx_CL;
     mp.q1zero_mask = pp.q1zero_mask;
+    mp.seq_off = c->db_has_x ? c->seq_off : nullptr;
+    mp.dbm2 = c->db_has_x ? c->dbm2 : nullptr;
     if (const char* dv = getenv("MUSC_DEBUG_MATCH")) mp.dbg = atoi(dv);
     for (int k = 0; k < pp.W && k < CTX_MAX_W; k++) mp.win[k] = pp.win[k];
     match_tables(mp);

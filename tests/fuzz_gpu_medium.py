@@ -23,6 +23,11 @@ from muscato_amd import Config, Engine, sorted_hits
 # MUSC_FUZZ_READS_X=1: X in the reads only (an X-free database: with at most two windows and reads
 # of at most 112 bases those runs take k_match_d's RX path whenever every read's X fit its xpos word)
 READS_X_ONLY = bool(os.environ.get("MUSC_FUZZ_READS_X"))
+# MUSC_FUZZ_DB_X=1: X in the database only, single bases and runs (N stretches), the reads sampled over
+# them get random bases there -- those runs stay on context buckets (k_match_t<.., XM = 2>: flagged
+# entries compared through the mask plane); =2: the reads keep the target's X where it falls outside
+# their windows (at most three per read), so read X meets target X
+DB_X = int(os.environ.get("MUSC_FUZZ_DB_X", "0"))
 KINDS = {0: 0, 1: 0, 2: 0, 3: 0}
 
 
@@ -45,7 +50,13 @@ def case(seed):
     T[nt - ncopy:] = T[rng.integers(0, nt - ncopy, size=ncopy)]
     sub = rng.random((ncopy, tlen)) < 0.03
     T[nt - ncopy:][sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
-    if xrate and not READS_X_ONLY:
+    if DB_X:
+        xrate = float(rng.choice([0.001, 0.004, 0.015]))
+        run = int(rng.choice([1, 1, 4, 40]))
+        starts = rng.random(T.shape) < xrate / run
+        for d in range(run):
+            T[:, d:][starts[:, :tlen - d]] = ord("X")
+    elif xrate and not READS_X_ONLY:
         T[rng.random(T.shape) < xrate] = ord("X")
     g = rng.integers(0, nt, size=nr)
     p = rng.integers(0, tlen - L + 1, size=nr)
@@ -54,6 +65,18 @@ def case(seed):
     R = T[g[:, None], p[:, None] + np.arange(L)[None, :]].copy()
     sub = rng.random(R.shape) < float(rng.choice([0.0, 0.01, 0.03]))
     R[sub] = bases[rng.integers(0, 4, size=int(sub.sum()))]
+    if DB_X:
+        isx = R == ord("X")
+        keep = np.zeros_like(isx)
+        if DB_X == 2:  # a read keeps the target's X outside its windows, three at most
+            inwin = np.zeros(L, dtype=bool)
+            for q in wins:
+                inwin[q:q + ww] = True
+            keep = isx & ~inwin[None, :]
+            keep &= np.cumsum(keep, axis=1) <= 3
+        fill = isx & ~keep
+        R[fill] = bases[rng.integers(0, 4, size=int(fill.sum()))]
+        xrate = 0.0
     if READS_X_ONLY:  # X (N in the FASTQ) in the reads alone, at rates where most reads keep a few of them
         xrate = float(rng.choice([0.002, 0.005, 0.02]))
     if xrate:
@@ -88,7 +111,7 @@ def main():
         if seed % 50 == 0:
             print("seed", seed, "hits", len(exp), "elapsed %.0fs" % (time.time() - t0), flush=True)
     print("fuzz_medium", lo, hi, "bad", bad, "in %.0fs" % (time.time() - t0), "index kinds used", KINDS,
-          "(reads-only X)" if READS_X_ONLY else "")
+          "(reads-only X)" if READS_X_ONLY else "(database X, mode %d)" % DB_X if DB_X else "")
 
 
 if __name__ == "__main__":

@@ -594,8 +594,8 @@ def test_block_screening_falls_back_to_exact_counters(eng):
 def test_index_selection(monkeypatch):
     """Which index a run gets (ensure_index): context buckets + the fused kernel when every read
     fits 120 bases (index_kind 1) or 200 bases (2: wide buckets) of context around each of at most
-    four windows and the database holds no X (reads may); the window-start buckets and k_screen ->
-    k_confirm otherwise -- with identical tuples either way."""
+    four windows (a database with X included: test_database_with_x_on_context_buckets); the
+    window-start buckets and k_screen -> k_confirm otherwise -- with identical tuples either way."""
     from muscato_amd import Config, Engine, sorted_hits
     monkeypatch.delenv("MUSC_INDEX", raising=False)
     monkeypatch.delenv("MUSC_MATCH", raising=False)
@@ -637,15 +637,21 @@ def test_index_selection(monkeypatch):
             got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
             assert eng.stats()["index_kind"] == kind, what
             assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
-        # a database with X: the two-kernel path
-        eng.load_targets([t[:50] + b"X" + t[51:] for t in targets[:3]] + targets[3:])
+        # a database with X keeps its context buckets (entries whose context touches an X are flagged and
+        # compared through the mask plane); MUSC_NO_X_CONTEXT=1 sends it to the two-kernel path as before
+        xt = [t[:50] + b"X" + t[51:] for t in targets[:3]] + targets[3:]
+        eng.load_targets(xt)
         reads = reads_of(100)
         ocfg = orc.Config(Windows=[0, 20], WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=100, MaxMatches=100000)
         eng.load_reads(reads)
         got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
-        assert eng.stats()["index_kind"] == 0
-        xt = [t[:50] + b"X" + t[51:] for t in targets[:3]] + targets[3:]
+        assert eng.stats()["index_kind"] == 1
         assert_same(got, as_arr(orc.match_direct(reads, xt, ocfg)))
+        monkeypatch.setenv("MUSC_NO_X_CONTEXT", "1")
+        got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+        assert eng.stats()["index_kind"] == 0
+        assert_same(got, as_arr(orc.match_direct(reads, xt, ocfg)))
+        monkeypatch.delenv("MUSC_NO_X_CONTEXT")
         eng.load_targets(targets)
         # forced
         monkeypatch.setenv("MUSC_INDEX", "classic")
@@ -662,6 +668,90 @@ def test_index_selection(monkeypatch):
         got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
         assert eng.stats()["index_kind"] == 1 and eng.stats()["ms_index_build"] == ms
         assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
+
+
+@pytest.mark.gpu
+def test_database_with_x_on_context_buckets(monkeypatch):
+    """A database with X (N in the FASTA) stays on context buckets: a window that holds an X is not
+    indexed, an entry whose context touches one is flagged and k_match_t<.., XM = 2> reads the target
+    span's mask plane for it -- X == X is a match, X against a base a mismatch
+    (cmd/muscato_confirm/main.go:151-159).  Reads with X keep the run there while every X is listed in
+    the read's xpos word and sits outside the run's windows; otherwise the two-kernel path takes over.
+    Every configuration against the direct oracle, the index kind asserted."""
+    from muscato_amd import Engine, sorted_hits
+    monkeypatch.delenv("MUSC_INDEX", raising=False)
+    monkeypatch.delenv("MUSC_MATCH", raising=False)
+    monkeypatch.delenv("MUSC_NO_X_CONTEXT", raising=False)
+
+    def sprinkle(rng, t, rate, run):
+        """X at `rate` per base, as runs of `run` bases"""
+        b = bytearray(t)
+        i = 0
+        while i < len(b):
+            if rng.random() < rate:
+                for j in range(i, min(len(b), i + run)):
+                    b[j] = ord("X")
+                i += run
+            i += 1
+        return bytes(b)
+
+    def reads_from(rng, targets, L, n, sub, keep_x, xfree_windows=None, ww=0):
+        out = set()
+        for _ in range(n):
+            t = rng.choice(targets)
+            if len(t) < L:
+                continue
+            u = rng.random()
+            p = 0 if u < 0.15 else (len(t) - L if u > 0.9 else rng.randint(0, len(t) - L))
+            r = bytearray(mutate(rng, t[p:p + L], sub, b"ACGT"))
+            for i in range(L):
+                x = t[p + i] == ord("X")
+                if x and keep_x:
+                    inwin = xfree_windows is not None and any(q <= i < q + ww for q in xfree_windows)
+                    r[i] = ord("X") if not inwin else ord("A")
+                elif x:
+                    r[i] = rng.choice(b"ACGT")
+            out.add(bytes(r))
+        return sorted(out)
+
+    # (what, windows, ww, read length, X rate, X run length, reads keep the target's X?, expected kind)
+    grid = [
+        ("isolated X, X-free reads", [0, 20], 12, 100, 0.004, 1, False, 1),
+        ("runs of 30 X, X-free reads", [0, 20], 12, 100, 0.002, 30, False, 1),
+        ("dense X, one window", [5], 10, 80, 0.02, 2, False, 1),
+        ("three windows at 100 bp: wide buckets", [0, 20, 40], 12, 100, 0.004, 3, False, 2),
+        ("150-bp reads: wide buckets", [0, 25], 14, 150, 0.003, 5, False, 2),
+        ("four windows, 15-mers", [0, 10, 20, 30], 15, 90, 0.004, 1, False, 1),
+        ("reads carry the target's X outside their windows", [0, 20], 12, 100, 0.004, 1, "outside", 1),
+        ("the same on wide buckets", [0, 20, 40], 12, 100, 0.004, 2, "outside", 2),
+        ("reads carry the target's X anywhere: some window holds one", [0, 20], 12, 100, 0.01, 1, True, 0),
+    ]
+    with Engine(0) as eng:
+        for gi, (what, wins, ww, L, rate, run, keep, kind) in enumerate(grid):
+            rng = random.Random(100 + gi)
+            base = [rand_seq(rng, rng.randint(L, 500), b"ACGT") for _ in range(30)]
+            base += [mutate(rng, rng.choice(base), 0.02, b"ACGT") for _ in range(15)]  # multi-map families
+            targets = [sprinkle(rng, t, rate, run) for t in base]
+            targets[0] = b"X" * 3 + targets[0][3:]                    # X at a target's start and end
+            targets[1] = targets[1][:-2] + b"XX"
+            assert any(b"X" in t for t in targets)
+            reads = reads_from(rng, targets, L, 600, 0.02, bool(keep), wins if keep == "outside" else None, ww)
+            if keep == "outside":
+                reads = [r for r in reads if r.count(b"X") <= 3]   # what an xpos word lists on either bucket width
+            total = covers = 0
+            for pm, mmtol in ((0.9, 1), (0.97, 0), (1.0, 0)):
+                ocfg = orc.Config(Windows=wins, WindowWidth=ww, PMatch=pm, MinDinuc=2, MaxReadLength=L, MaxMatches=100000, MMTol=mmtol)
+                full = orc.match_direct(reads, targets, ocfg)
+                total += len(full)
+                covers += sum(b"X" in targets[g][p:p + len(reads[r])] for r, g, p, _ in full)
+                got = gpu_hits(eng, ocfg, reads, targets, False)
+                assert eng.stats()["index_kind"] == kind, what
+                assert_same(got, as_arr(full))
+                got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=True))
+                assert_same(got, as_arr(orc.best_filter(full, ocfg.MMTol)))
+            if kind:
+                # the flagged entries matter: accepted placements cover an X of their target
+                assert total > 300 and covers > 20, what
 
 
 @pytest.mark.gpu
