@@ -189,6 +189,8 @@ def main() -> int:
                     help="classic: force the 64-byte-bucket index and the two-kernel path (MUSC_INDEX=classic)")
     ap.add_argument("--x-reads-only", action="store_true",
                     help="with --xrate: X (N in the FASTQ) in the reads alone, the database stays X-free (reads with X on context buckets)")
+    ap.add_argument("--x-db-only", action="store_true",
+                    help="with --xrate: X (N in the FASTA) in the database alone; the reads sampled over one get a random base there")
     ap.add_argument("--xrate", type=float, default=0.0,
                     help="fraction of bases replaced by X in targets and reads (the correctness/timing run with the mask planes)")
     args = ap.parse_args()
@@ -273,7 +275,13 @@ def main() -> int:
     t0 = time.time()
     U = wl.n_unique_reads
     reads = synth.gen_unique_reads(wl, targets, device, seed + 7919 * (rank + 1))
-    if args.xrate > 0:
+    if args.xrate > 0 and args.x_db_only:
+        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+        for s0 in range(0, reads.shape[0], 1_000_000):
+            blk = reads[s0:s0 + 1_000_000]
+            isx = blk == ord("X")
+            blk[isx] = acgt[torch.randint(0, 4, (int(isx.sum()),), device=device, generator=gx)]
+    elif args.xrate > 0:
         for s0 in range(0, reads.shape[0], 1_000_000):
             blk = reads[s0:s0 + 1_000_000]
             blk[torch.rand(blk.shape, device=device, generator=gx) < args.xrate] = ord("X")
@@ -673,7 +681,7 @@ def main() -> int:
                 "targets": wl.n_targets, "target_len": wl.target_len, "read_len": wl.read_len,
                 "Windows": list(wl.windows), "WindowWidth": wl.window_width, "PMatch": wl.pmatch,
                 "MMTol": wl.mmtol, "MinDinuc": wl.min_dinuc, "MaxMatches": wl.max_matches,
-                "MatchMode": wl.match_mode, "x_rate": args.xrate, "x_in": ("reads" if args.x_reads_only else "reads and database") if args.xrate else None, "read_order": "random" if args.unsorted else "bytewise sorted (reads_sorted)",
+                "MatchMode": wl.match_mode, "x_rate": args.xrate, "x_in": ("reads" if args.x_reads_only else "database" if args.x_db_only else "reads and database") if args.xrate else None, "read_order": "random" if args.unsorted else "bytewise sorted (reads_sorted)",
                 "parallelism": "reads sharded x%d, database replicated" % world, "gather": gather_mode,
                 "timed_region": "`value`: steady state -- unique reads + database + index resident in HBM -> hits in HBM"
                                 + (" gathered on rank 0 (RCCL, gather of pass i overlapped with pass i+1)" if world > 1 else "")

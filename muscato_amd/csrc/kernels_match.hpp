@@ -18,8 +18,20 @@
 // a hashed table exact (a colliding key fails the window comparison) -- is compared from the line
 // the probe fetched (cmd/muscato_confirm/main.go:151-159, 205-211).  Usable when
 // CL - min(q1) + max read length <= 120 (Windows 0,20 + 100-bp reads: exactly 120), at most
-// CTX_MAX_W windows, no X in reads or database, database below 2^32 bases; everything else takes
-// the classic path.  Entries beyond a bucket's third live in E as 40-byte CtxEntry.
+// CTX_MAX_W windows, database below 2^32 bases; everything else takes the classic path.  Entries
+// beyond a bucket's third live in E as 40-byte CtxEntry.
+// A DATABASE WITH X (N in the FASTA): the context is a 2-bit stream and cannot hold an X, so
+//   * a window that holds an X is not indexed (a read window without X never equals it; runs whose
+//     read windows hold an X take the classic path, k_xpos_check_db), and
+//   * an entry whose context holds an X of its target carries CTX_XFLAG in its jx word (targets are
+//     shorter than 2^31 bases) and lists up to two of them by their context position: the first in the
+//     top byte of its gene word (at most 2^24 targets), the second (CTX_XNONE if there is none) in the
+//     top byte of its last context word, whose distance to the target end then saturates at 255 (reads
+//     on this path are at most 200 bases: every comparison against it stays exact) -- the usual case:
+//     k_match_t<.., XM = 2> sets the bits in registers.  Three and more: CTX_XMANY in the gene word,
+//     and the kernel reads the mask plane of the target span (seq_off[gene] + jx - CL,
+//     MatchParams.seq_off / dbm2).  Compared as cdiff does: X == X is a match, X against a base a
+//     mismatch (cmd/muscato_confirm/main.go:151-159).
 // The table has 4^ww buckets (key = bucket, exact) when that is at most twice the database's
 // window count, else about one bucket per base under a 64-bit mix: 1 Gbp -> 2^30 x 128 B =
 // 128 GiB, 100 Mbp -> 2^27 x 128 B = 16 GiB.
@@ -27,7 +39,9 @@
 #define CTX_BASES 120
 #define CTX_INLINE 3
 #define CTX_MAX_W 4
-#define CTX_XFLAG 0x80000000u  // in an entry's jx word: the context overlaps an X of the database
+#define CTX_XFLAG 0x80000000u  // in an entry's jx word: the context holds an X of its target ...
+#define CTX_XMANY 0xFFu        // ... top byte of the gene word: where (context base 0..199), or CTX_XMANY = three and more
+#define CTX_XNONE 0xFFu        // ... top byte of the last context word: where the second one is, or CTX_XNONE
 
 struct __attribute__((aligned(128))) CtxBucket {
   uint32_t count;
@@ -76,6 +90,14 @@ __host__ __device__ inline uint64_t ctx_entry_word(uint32_t i) {
 // bytes of E for n overflow entries
 inline uint64_t ctx_entries_bytes(uint64_t n, bool wide) { return (wide ? (n + 1) / 2 : (n + 2) / 3) * 128ull; }
 
+// bits [lo, hi) of a 32-bit word as a mask, for any int lo / hi (host and device)
+__host__ __device__ inline uint32_t bit_range_mask(int lo, int hi) {
+  if (hi <= 0 || lo >= 32 || hi <= lo) return 0u;
+  const uint32_t mh = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
+  const uint32_t ml = lo <= 0 ? 0xFFFFFFFFu : ~((1u << lo) - 1u);
+  return mh & ml;
+}
+
 // 64 bits of the stream from a possibly negative bit offset (zeros before the stream start)
 DEV uint64_t ext64s(const uint32_t* __restrict__ w, long long bo) {
   if (bo >= 0) return ext64(w, (uint64_t)bo);
@@ -112,6 +134,14 @@ DEV bool plane_any_x(const uint32_t* __restrict__ dbm2, uint64_t g, uint32_t n) 
 }
 
 // dbm2 / dbx: the database's mask plane and its X-block bitmap, or null for a database without X
+// the last context word of a flagged entry: context bits | min(distance to the target end, 255) << 16 | the second X's place << 24
+DEV uint32_t ctx_xtail(uint32_t w, uint32_t xtail) {
+  const uint32_t rem = w >> 16;
+  return (w & 0xFFFFu) | ((rem > 255u ? 255u : rem) << 16) | ((xtail & 0xFFu) << 24);
+}
+// what a kernel reads back of it
+DEV uint32_t ctx_rem(uint32_t w, bool flagged) { return flagged ? (w >> 16) & 0xFFu : w >> 16; }
+
 template <bool SCATTER, bool WIDE>
 __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ db2, const uint32_t* __restrict__ dbm2,
                                                    const uint32_t* __restrict__ dbx,
@@ -140,14 +170,40 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
     const uint64_t s = seq_off[gene], e = seq_off[gene + 1];
     const uint64_t jx = g - s;
     if (jx + (uint64_t)ww > e - s) continue;  // window would cross the target end
-    uint32_t xflag = 0;
+    uint32_t xflag = 0, xgene = 0, xtail = 0;  // xtail: 0x100 | the second X's place, for a flagged entry
     if (dbx) {
-      // a window with an X has no key here; an entry whose context span (clipped to the database)
-      // touches a block with an X is flagged -- conservative, the kernel then consults the plane
+      // a window with an X has no key here; an entry whose context holds an X of its own target is
+      // flagged, with the position of the X (or CTX_XMANY) in the top byte of the gene word
       if (db_span_has_x(dbx, g, (uint32_t)ww) && plane_any_x(dbm2, g, (uint32_t)ww)) continue;
-      const long long lo = (long long)g - (long long)CL, hi = lo + (WIDE ? CTXW_BASES : CTX_BASES);
+      constexpr int NB = WIDE ? CTXW_BASES : CTX_BASES;
+      const long long lo = (long long)g - (long long)CL, hi = lo + NB;
       const uint64_t c0 = lo > 0 ? (uint64_t)lo : 0ull, c1 = (uint64_t)hi < nbases ? (uint64_t)hi : nbases;
-      if (db_span_has_x(dbx, c0, (uint32_t)(c1 - c0))) xflag = CTX_XFLAG;
+      if (SCATTER && db_span_has_x(dbx, c0, (uint32_t)(c1 - c0))) {
+        // context base c is global base lo + c: inside the target for c in [tlo, thi)
+        const int tlo = (long long)s > lo ? (int)((long long)s - lo) : 0;
+        const int thi = (long long)e < hi ? (int)((long long)e - lo) : NB;
+        uint32_t nx = 0, where = 0, where2 = CTX_XNONE;
+#pragma unroll
+        for (int j = 0; j < (NB + 15) / 16; j++) {
+          uint32_t m = (uint32_t)ext64s(dbm2, 2 * lo + 32 * j) & 0x55555555u & bit_range_mask(2 * tlo - 32 * j, 2 * thi - 32 * j);
+          nx += (uint32_t)__popc(m);
+          if (m && where2 == CTX_XNONE) {
+            const uint32_t p = 16u * (uint32_t)j + (((uint32_t)__ffs(m) - 1u) >> 1);
+            if (nx == (uint32_t)__popc(m)) {  // the first X of the context is in this word
+              where = p;
+              m &= m - 1u;
+              if (m) where2 = 16u * (uint32_t)j + (((uint32_t)__ffs(m) - 1u) >> 1);
+            } else {
+              where2 = p;
+            }
+          }
+        }
+        if (nx) {
+          xflag = CTX_XFLAG;
+          xgene = (nx <= 2 ? where : CTX_XMANY) << 24;
+          xtail = 0x100u | where2;
+        }
+      }
     }
     const uint32_t b = bucket_of(db2, nullptr, 2 * g, ww, bits, direct);
     if (!SCATTER) {
@@ -157,9 +213,10 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
       if constexpr (WIDE) {
         CtxBucketW* const TW = reinterpret_cast<CtxBucketW*>(T);
         CtxEntryW ent;
-        ent.gene = gene;
+        ent.gene = gene | xgene;
         ent.jx = (uint32_t)jx | xflag;
         ctx_words<CTXW_WORDS>(db2, g, e, CL, ent.ctx);
+        if (xtail) ent.ctx[CTXW_WORDS - 1] = ctx_xtail(ent.ctx[CTXW_WORDS - 1], xtail);
         uint32_t* pw = slot < CTXW_INLINE ? reinterpret_cast<uint32_t*>(&TW[b].e[slot])
                                           : reinterpret_cast<uint32_t*>(Ev) + ctx_entry_word<true>(TW[b].ovf + (slot - CTXW_INLINE));
         pw[0] = ent.gene;
@@ -169,15 +226,16 @@ __global__ __launch_bounds__(256) void k_index_ctx(const uint32_t* __restrict__ 
       } else {
         uint32_t c[8];
         ctx_words<8>(db2, g, e, CL, c);
+        if (xtail) c[7] = ctx_xtail(c[7], xtail);
         if (slot < CTX_INLINE) {
-          T[b].gene[slot] = gene;
+          T[b].gene[slot] = gene | xgene;
           T[b].jx[slot] = (uint32_t)jx | xflag;
           uint4* dst = reinterpret_cast<uint4*>(T[b].ctx[slot]);
           dst[0] = make_uint4(c[0], c[1], c[2], c[3]);
           dst[1] = make_uint4(c[4], c[5], c[6], c[7]);
         } else {
           uint32_t* p = reinterpret_cast<uint32_t*>(Ev) + ctx_entry_word<false>(T[b].ovf + (slot - CTX_INLINE));
-          p[0] = gene;
+          p[0] = gene | xgene;
           p[1] = (uint32_t)jx | xflag;
 #pragma unroll
           for (int i = 0; i < 8; i++) p[2 + i] = c[i];
@@ -230,13 +288,6 @@ struct MatchParams {
   uint32_t lm[CTXW_BASES + 1][CTX_MAX_W][CTXW_WORDS];
 };
 
-// bits [lo, hi) of a 32-bit word as a mask, for any int lo / hi (host and device)
-__host__ __device__ inline uint32_t bit_range_mask(int lo, int hi) {
-  if (hi <= 0 || lo >= 32 || hi <= lo) return 0u;
-  const uint32_t mh = hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u);
-  const uint32_t ml = lo <= 0 ? 0xFFFFFFFFu : ~((1u << lo) - 1u);
-  return mh & ml;
-}
 
 // host: the mask tables of a parameter block whose scalar fields are set
 inline void match_tables(MatchParams& mp) {

@@ -332,10 +332,20 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   // a database with X: the X of the target span an entry's context covers, in the context's coordinates
   // (one bit per base, as xm) -- read from the mask plane for the lanes whose entry is flagged, zero for
   // the others.  A rare path: its loads wait on the spot.
-  auto target_xmask = [&](bool want, uint32_t gene, uint32_t jx, uint32_t (&tm)[NW]) __attribute__((always_inline)) {
+  // xi = 0 for an entry without the flag, else 0x100 | the top byte of its gene word: the context position
+  // of the entry's one X (set here, in registers), or CTX_XMANY
+  // and clast = the entry's last context word, whose top byte lists a second X (CTX_XNONE: there is none)
+  auto target_xmask = [&](bool ok, uint32_t xi, uint32_t clast, uint32_t gene, uint32_t jx, uint32_t (&tm)[NW]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NW; j++) tm[j] = 0;
     if constexpr (DBX) {
+      if (!__any(ok && xi)) return;
+      const uint32_t xp = xi & 0xFFu, xp2 = clast >> 24;
+      const bool one = ok && xi && xp != CTX_XMANY, two = one && xp2 != CTX_XNONE;
+      const uint32_t bit = one ? 1u << (2u * (xp & 15u)) : 0u, bit2 = two ? 1u << (2u * (xp2 & 15u)) : 0u;
+#pragma unroll
+      for (int j = 0; j < NW; j++) tm[j] = ((xp >> 4) == (uint32_t)j ? bit : 0u) | ((xp2 >> 4) == (uint32_t)j ? bit2 : 0u);
+      const bool want = ok && xi && xp == CTX_XMANY;
       if (__any(want)) {
         if (want) {
           const uint64_t* __restrict__ so = mp->seq_off;
@@ -359,17 +369,18 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     else return base_diff(x, lmj);
   };
   auto score = [&](bool live, int k, int q1, const uint32_t (&img)[NW], const WinTab& tb, const uint32_t (&xm)[NW], uint32_t gene, uint32_t jx,
-                   bool xf, const uint32_t (&c)[NW], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
+                   uint32_t xi, const uint32_t (&c)[NW], int len, uint32_t budget, uint32_t valid, uint32_t slot) __attribute__((always_inline)) -> uint32_t {
     // a placement must start inside the target (p = jx - q1 >= 0) and end inside it; the pos-0 rules
     // (ctx_fit) are evaluated only when some lane of the wave is at p == 0 or at target position 0
     uint32_t z = 0;
     bool ok;
-    if (__any(live && (jx == (uint32_t)q1 || jx == 0u))) ok = live & ctx_fit(jx, c[NW - 1] >> 16, q1, ww, len, &z);
-    else ok = live & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[NW - 1] >> 16));
+    const uint32_t rem = DBX ? ctx_rem(c[NW - 1], xi != 0) : c[NW - 1] >> 16;
+    if (__any(live && (jx == (uint32_t)q1 || jx == 0u))) ok = live & ctx_fit(jx, rem, q1, ww, len, &z);
+    else ok = live & (jx >= (uint32_t)q1) & (len - q1 <= (int)rem);
     ncmp += ok ? 1u : 0u;
     uint32_t w = NX_REJECT;
     uint32_t tm[NW];
-    target_xmask(ok && xf, gene, jx, tm);
+    target_xmask(ok, xi, c[NW - 1], gene, jx, tm);
     if (ok) {
       uint32_t d[NW], nx = 0;
 #pragma unroll
@@ -513,8 +524,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       if (!__any(have)) return;
       const int len = (int)REC_LEN(meta);
       // the entry's words: gene, jx, ctx[NW]
-      const uint32_t gene = eq[0].x, jx = DBX ? eq[0].y & ~CTX_XFLAG : eq[0].y;
-      const bool xf = DBX && (eq[0].y & CTX_XFLAG) != 0;
+      const uint32_t xi = DBX && (eq[0].y & CTX_XFLAG) ? 0x100u | (eq[0].x >> 24) : 0u;
+      const uint32_t gene = xi ? eq[0].x & 0xFFFFFFu : eq[0].x, jx = DBX ? eq[0].y & ~CTX_XFLAG : eq[0].y;
       uint32_t c[NW];
 #pragma unroll
       for (int j = 0; j < NW; j++) {
@@ -547,12 +558,13 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         }
         uint32_t z = 0;
         bool ok;
-        if (__any(have && (jx == (uint32_t)q1 || jx == 0u))) ok = have & ctx_fit(jx, c[NW - 1] >> 16, q1, ww, len, &z);
-        else ok = have & (jx >= (uint32_t)q1) & (len - q1 <= (int)(c[NW - 1] >> 16));
+        const uint32_t rem = DBX ? ctx_rem(c[NW - 1], xi != 0) : c[NW - 1] >> 16;
+        if (__any(have && (jx == (uint32_t)q1 || jx == 0u))) ok = have & ctx_fit(jx, rem, q1, ww, len, &z);
+        else ok = have & (jx >= (uint32_t)q1) & (len - q1 <= (int)rem);
         ncmp += ok ? 1u : 0u;
         uint32_t w = NX_REJECT;
         uint32_t tm[NW];
-        target_xmask(ok && xf, gene, jx, tm);
+        target_xmask(ok, xi, c[NW - 1], gene, jx, tm);
         if (ok) {
           uint32_t ia[NW], ib[NW], xm[NW];
           read_image_n<RW, NW>(rec, sha, ia);
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         uint32_t img[NW], xm[NW];
         read_image_n<RW, NW>(rec, shk, img);
         x_mask(xw, shk, xm);
-        const uint32_t w2 = score(mine, kk, q1k, img, tb, xm, gene, jx, xf, c, len, REC_BUDGET(meta), REC_VALID(meta), seg);
+        const uint32_t w2 = score(mine, kk, q1k, img, tb, xm, gene, jx, xi, c, len, REC_BUDGET(meta), REC_VALID(meta), seg);
         if (mine) {
           w = w2;
           q1 = q1k;
@@ -929,11 +941,12 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
               na = line_l[rb ^ (uint32_t)(2 * s + 4)];
               nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
             }
-            const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
+            const uint32_t gener = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
             const uint32_t jxr = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
-            const uint32_t jx = DBX ? jxr & ~CTX_XFLAG : jxr;
+            const uint32_t xi = DBX && (jxr & CTX_XFLAG) ? 0x100u | (gener >> 24) : 0u;
+            const uint32_t gene = xi ? gener & 0xFFFFFFu : gener, jx = DBX ? jxr & ~CTX_XFLAG : jxr;
             const uint32_t c[NW] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-            const uint32_t w = score(live, k, q1, img, tb, xm, gene, jx, DBX && (jxr & CTX_XFLAG) != 0, c, rlen, budget, valid_cur, lane);
+            const uint32_t w = score(live, k, q1, img, tb, xm, gene, jx, xi, c, rlen, budget, valid_cur, lane);
             report_own(w, gene, jx - (uint32_t)q1, wc[k]);
             ca = na;
             cb = nb;
@@ -948,9 +961,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
             if (__any(live)) {
               const uint4 c2 = line_l[rb ^ 2u], c3 = line_l[rb ^ 3u];
               const uint32_t c[NW] = {h1.x, h1.y, h1.z, h1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, m4.x};
-              const uint32_t jx = DBX ? h0.w & ~CTX_XFLAG : h0.w;
-              const uint32_t w = score(live, k, q1, img, tb, xm, h0.z, jx, DBX && (h0.w & CTX_XFLAG) != 0, c, rlen, budget, valid_cur, lane);
-              report_own(w, h0.z, jx - (uint32_t)q1, wc[k]);
+              const uint32_t xi = DBX && (h0.w & CTX_XFLAG) ? 0x100u | (h0.z >> 24) : 0u;
+              const uint32_t gene = xi ? h0.z & 0xFFFFFFu : h0.z, jx = DBX ? h0.w & ~CTX_XFLAG : h0.w;
+              const uint32_t w = score(live, k, q1, img, tb, xm, gene, jx, xi, c, rlen, budget, valid_cur, lane);
+              report_own(w, gene, jx - (uint32_t)q1, wc[k]);
             }
           }
           {
@@ -958,9 +972,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
             if (__any(live)) {
               const uint4 c5 = line_l[rb ^ 5u], c6 = line_l[rb ^ 6u], c7 = line_l[rb ^ 7u];
               const uint32_t c[NW] = {m4.w, c5.x, c5.y, c5.z, c5.w, c6.x, c6.y, c6.z, c6.w, c7.x, c7.y, c7.z, c7.w};
-              const uint32_t jx = DBX ? m4.z & ~CTX_XFLAG : m4.z;
-              const uint32_t w = score(live, k, q1, img, tb, xm, m4.y, jx, DBX && (m4.z & CTX_XFLAG) != 0, c, rlen, budget, valid_cur, lane);
-              report_own(w, m4.y, jx - (uint32_t)q1, wc[k]);
+              const uint32_t xi = DBX && (m4.z & CTX_XFLAG) ? 0x100u | (m4.y >> 24) : 0u;
+              const uint32_t gene = xi ? m4.y & 0xFFFFFFu : m4.y, jx = DBX ? m4.z & ~CTX_XFLAG : m4.z;
+              const uint32_t w = score(live, k, q1, img, tb, xm, gene, jx, xi, c, rlen, budget, valid_cur, lane);
+              report_own(w, gene, jx - (uint32_t)q1, wc[k]);
             }
           }
         }

@@ -1134,9 +1134,9 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
   // (the planes themselves may exist without an X: an all-zero one is made for the side that has
   // none when the other side does, and the database's stays for the context's lifetime)
   const bool lane = match_kind(c, P->n_windows) != MK_QUAD;
-  // a database with X: k_match_t only (entries whose context touches an X are flagged in bit 31 of
-  // their position and compared through the mask plane)
-  if (c->db_has_x && (!lane || c->max_tlen >= 0x80000000ull || getenv("MUSC_NO_X_CONTEXT"))) return false;
+  // a database with X: k_match_t only (an entry whose context holds an X is flagged in bit 31 of its
+  // position, the X's place or "several: see the mask plane" in the top byte of its target number)
+  if (c->db_has_x && (!lane || c->max_tlen >= 0x80000000ull || c->nseq > (1u << 24) || getenv("MUSC_NO_X_CONTEXT"))) return false;
   if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
   if (P->n_windows > CTX_MAX_W) return false;
   int q1min = P->windows[0], q1max = P->windows[0];
