@@ -585,7 +585,9 @@ def main() -> int:
     legs["cold_pass_device_ms"] = cold_device_ms
 
     rc = 0
-    tkey = args.workload + ("_classic" if args.index == "classic" else "")  # the workload's entry in TRAFFIC_FILE
+    # the workload's entry in TRAFFIC_FILE (runs with X have entries of their own: profiles/collect.sh cfg3xdb cfg3xreads)
+    tkey = args.workload + (("xdb" if args.x_db_only else "xreads" if args.x_reads_only else "x") if args.xrate else "")
+    tkey += "_classic" if args.index == "classic" or (args.xrate and os.environ.get("MUSC_NO_X_CONTEXT")) else ""
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         total_raw = wl.total_raw_reads if strong else wl.n_raw_reads * world

@@ -17,6 +17,9 @@ MUSC_GRAPH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-survey
 # reads with X (0.1 % of the read bases; the database stays X-free): context buckets (k_match_t, RX) and the two-kernel path
 python bench.py --xrate 0.001 --x-reads-only --no-cpu-baseline --no-survey-scope --steps 10 > $o/${tag}_cfg3_xreads_bench.json 2>/dev/null || echo "cfg3 xreads FAILED"
 MUSC_NO_X_CONTEXT=1 python bench.py --xrate 0.001 --x-reads-only --no-cpu-baseline --no-survey-scope --steps 10 > $o/${tag}_cfg3_xreads_classic_bench.json 2>/dev/null || echo "cfg3 xreads classic FAILED"
+# a database with X (0.1 % of its bases; the reads sampled over one get a random base there): context buckets (k_match_t, XM = 2) and the two-kernel path
+python bench.py --xrate 0.001 --x-db-only --no-cpu-baseline --no-survey-scope --steps 10 > $o/${tag}_cfg3_xdb_bench.json 2>/dev/null || echo "cfg3 xdb FAILED"
+MUSC_NO_X_CONTEXT=1 python bench.py --xrate 0.001 --x-db-only --no-cpu-baseline --no-survey-scope --steps 10 > $o/${tag}_cfg3_xdb_classic_bench.json 2>/dev/null || echo "cfg3 xdb classic FAILED"
 # runs beyond 120 bases of context: wide context buckets, and the two-kernel path they took before
 for wl in cfg3w3 cfg3r150; do
   python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_${wl}_bench.json 2>/dev/null || echo "$wl FAILED"

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect a round's profile evidence on the GPU box (run from the repo root through gpurun):
-#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150
+#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150 (also: cfg3xdb cfg3xreads)
 # Per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --steps 5` (kernel
 # statistics + the JSON line of that very run), then separate --pmc passes (never combined with a
 # trace; one counter group per pass; the program directly after `--`) for HBM traffic.  cfg3 also gets
-# the two-kernel path (--index classic), the second fused kernel (MUSC_MATCH=quad), the SQ
-# instruction mix and a --memory-copy-trace run of the SURVEY-scope leg.  Raw output stays under
+# the two-kernel path (--index classic) and the second fused kernel (MUSC_MATCH=quad); the SQ
+# instruction mix is profiles/pmc_sq.sh.  Raw output stays under
 # gpurun_out/prof_<tag>/; the summaries land in gpurun_out/<tag>_* -- copy those into profiles/.
 set -o pipefail
 tag=${1:-r03}; shift
@@ -17,8 +17,12 @@ echo "{" > gpurun_out/${tag}_traffic.json.parts
 first=1
 for wl in $wls; do
   kinds="auto"; [ "$wl" = "cfg3" ] && kinds="auto classic"
+  # cfg3 with 0.1 % X: in the database alone (cfg3xdb: context buckets, k_match_t<.., XM = 2>), in the reads alone (cfg3xreads: XM = 1)
+  bwl=$wl; xflags=""
+  [ "$wl" = "cfg3xdb" ] && { bwl=cfg3; xflags="--xrate 0.001 --x-db-only"; }
+  [ "$wl" = "cfg3xreads" ] && { bwl=cfg3; xflags="--xrate 0.001 --x-reads-only"; }
   for kind in $kinds; do
-    B="python3 bench.py --workload $wl --no-cpu-baseline --no-survey-scope --index $kind"
+    B="python3 bench.py --workload $bwl $xflags --no-cpu-baseline --no-survey-scope --index $kind"
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_${wl}_$kind -- $B --steps 5 > $out/stats_${wl}_$kind.log 2>&1 || { tail -5 $out/stats_${wl}_$kind.log; exit 1; }
     f=$(find $out/stats_${wl}_$kind -name "*kernel_stats.csv" | head -1)
     grep -E "^\"?Name|k_" "$f" > gpurun_out/${tag}_${wl}_${kind}_kernel_stats.csv
@@ -58,9 +62,7 @@ if echo " $wls " | grep -q " cfg3 "; then
   MUSC_MATCH=quad timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_quad -- python3 bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 5 > $out/stats_quad.log 2>&1 || tail -3 $out/stats_quad.log
   f=$(find $out/stats_quad -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && grep -E "^\"?Name|k_" "$f" > gpurun_out/${tag}_cfg3_quad_kernel_stats.csv
-  # the SURVEY-scope leg: copies and kernels on one time line (no counters in this run)
-  timeout -k 10 300 rocprofv3 --memory-copy-trace --kernel-trace --stats --output-format csv -d $out/copies -- python3 bench.py --workload cfg3 --no-cpu-baseline --steps 2 > $out/copies.log 2>&1 || tail -3 $out/copies.log
-  python3 profiles/overlap_from_trace.py $out/copies > gpurun_out/${tag}_cfg3_survey_scope_overlap.txt 2>&1 || true
+  # (no copy + kernel time line of the SURVEY-scope leg: rocprofv3 --memory-copy-trace dies at exit on this image, profiles/README.md)
   rm -rf $out/stats_quad/*/*.db 2>/dev/null
 fi
 du -sh $out
