@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect a round's profile evidence on the GPU box (run from the repo root through gpurun):
-#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150 (also: cfg3xdb cfg3xreads)
+#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150 (also: cfg3xdb cfg3xreads cfg3xdb_classic cfg3xreads_classic)
 # Per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --steps 5` (kernel
 # statistics + the JSON line of that very run), then separate --pmc passes (never combined with a
 # trace; one counter group per pass; the program directly after `--`) for HBM traffic.  cfg3 also gets
@@ -19,8 +19,13 @@ for wl in $wls; do
   kinds="auto"; [ "$wl" = "cfg3" ] && kinds="auto classic"
   # cfg3 with 0.1 % X: in the database alone (cfg3xdb: context buckets, k_match_t<.., XM = 2>), in the reads alone (cfg3xreads: XM = 1)
   bwl=$wl; xflags=""
-  [ "$wl" = "cfg3xdb" ] && { bwl=cfg3; xflags="--xrate 0.001 --x-db-only"; }
-  [ "$wl" = "cfg3xreads" ] && { bwl=cfg3; xflags="--xrate 0.001 --x-reads-only"; }
+  unset MUSC_NO_X_CONTEXT
+  case "$wl" in
+    cfg3xdb*) bwl=cfg3; xflags="--xrate 0.001 --x-db-only";;
+    cfg3xreads*) bwl=cfg3; xflags="--xrate 0.001 --x-reads-only";;
+  esac
+  # (..._classic: the same run kept off the context buckets -- the two-kernel path it took before)
+  case "$wl" in cfg3x*_classic) export MUSC_NO_X_CONTEXT=1;; esac
   for kind in $kinds; do
     B="python3 bench.py --workload $bwl $xflags --no-cpu-baseline --no-survey-scope --index $kind"
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_${wl}_$kind -- $B --steps 5 > $out/stats_${wl}_$kind.log 2>&1 || { tail -5 $out/stats_${wl}_$kind.log; exit 1; }
