@@ -587,7 +587,8 @@ def main() -> int:
     rc = 0
     # the workload's entry in TRAFFIC_FILE (runs with X have entries of their own: profiles/collect.sh cfg3xdb cfg3xreads)
     tkey = args.workload + (("xdb" if args.x_db_only else "xreads" if args.x_reads_only else "x") if args.xrate else "")
-    tkey += "_classic" if args.index == "classic" or (args.xrate and os.environ.get("MUSC_NO_X_CONTEXT")) else ""
+    tkey += "_classic" if (args.index == "classic" or (args.xrate and os.environ.get("MUSC_NO_X_CONTEXT"))
+                           or os.environ.get("MUSC_CONTEXT") == "narrow") else ""
     if rank == 0:
         ms_step = elapsed * 1e3 / args.steps
         total_raw = wl.total_raw_reads if strong else wl.n_raw_reads * world

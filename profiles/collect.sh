@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect a round's profile evidence on the GPU box (run from the repo root through gpurun):
-#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150 (also: cfg3xdb cfg3xreads cfg3xdb_classic cfg3xreads_classic)
+#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150 (also: cfg3xdb cfg3xreads cfg3xdb_classic cfg3xreads_classic cfg3w3_classic cfg3r150_classic)
 # Per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --steps 5` (kernel
 # statistics + the JSON line of that very run), then separate --pmc passes (never combined with a
 # trace; one counter group per pass; the program directly after `--`) for HBM traffic.  cfg3 also gets
@@ -26,6 +26,9 @@ for wl in $wls; do
   esac
   # (..._classic: the same run kept off the context buckets -- the two-kernel path it took before)
   case "$wl" in cfg3x*_classic) export MUSC_NO_X_CONTEXT=1;; esac
+  # (cfg3w3_classic, cfg3r150_classic: the wide-bucket workloads on the two-kernel path they took before r03)
+  unset MUSC_CONTEXT
+  case "$wl" in cfg3w3_classic|cfg3r150_classic) bwl=${wl%_classic}; export MUSC_CONTEXT=narrow;; esac
   for kind in $kinds; do
     B="python3 bench.py --workload $bwl $xflags --no-cpu-baseline --no-survey-scope --index $kind"
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_${wl}_$kind -- $B --steps 5 > $out/stats_${wl}_$kind.log 2>&1 || { tail -5 $out/stats_${wl}_$kind.log; exit 1; }

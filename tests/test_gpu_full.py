@@ -214,3 +214,108 @@ def test_baseline_config_at_full_size(name, index, monkeypatch):
     np.minimum.at(bmin, exp[:, 0], exp[:, 3].astype(np.int64))
     bexp = exp[exp[:, 3] <= bmin[exp[:, 0]] + wl.mmtol]
     assert bestg.shape == bexp.shape and (bestg == bexp).all(), "best+MMTol differs from the oracle on the sample"
+
+
+def test_cfg3_with_x_in_the_database_at_full_size(monkeypatch):
+    """BASELINE configs[2] with 0.1 % of the database's bases X (N in the FASTA), at full size: the
+    context-bucket path (index kind 1: k_match_t<.., XM = 2>, flagged entries) and the two-kernel path
+    (MUSC_NO_X_CONTEXT=1: mask planes in k_confirm) are two implementations of cdiff's X rule
+    (cmd/muscato_confirm/main.go:151-159) -- they must return the same tuples, every one a real
+    placement whose nmiss is the Hamming distance with every X of the target counted as a mismatch
+    (the reads hold none), the union a set, no MaxMatches overflow; and a sample agrees with the
+    literal oracle tuple for tuple."""
+    import torch
+    from muscato_amd import Config, Engine, sorted_hits, synth
+    from oracle import literal
+    monkeypatch.delenv("MUSC_MATCH", raising=False)
+    monkeypatch.delenv("MUSC_INDEX", raising=False)
+    monkeypatch.delenv("MUSC_NO_X_CONTEXT", raising=False)
+    wl = synth.WORKLOADS["cfg3"]
+    dev = torch.device("cuda", 0)
+    L, TL, NT = wl.read_len, wl.target_len, wl.n_targets
+    budget = int((1.0 - wl.pmatch) * L)
+    seed = synth.SEED_BASE + 4242
+    cfg = Config(Windows=list(wl.windows), WindowWidth=wl.window_width, PMatch=wl.pmatch, MinDinuc=wl.min_dinuc,
+                 MaxReadLength=L, MaxMatches=wl.max_matches, MMTol=wl.mmtol, MatchMode=wl.match_mode)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    T = synth.gen_targets(wl, dev, seed)
+    for s0 in range(0, NT, 100_000):
+        blk = T[s0:s0 + 100_000]
+        blk[torch.rand(blk.shape, device=dev, generator=g) < 0.001] = ord("X")
+    # a few runs of X as well (the edge of a run gives contexts with three and more X: the mask-plane path)
+    starts = torch.randint(0, NT * TL - 64, (20_000,), device=dev, generator=g)
+    flat = T.reshape(-1)
+    for d in range(40):
+        flat[starts + d] = ord("X")
+    toff = synth.offsets_for(NT, TL, dev)
+    raw = synth.gen_unique_reads(wl, T, dev, seed + 7919)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    for s0 in range(0, raw.shape[0], 1_000_000):
+        blk = raw[s0:s0 + 1_000_000]
+        isx = blk == ord("X")
+        blk[isx] = acgt[torch.randint(0, 4, (int(isx.sum()),), device=dev, generator=g)]
+    nraw = raw.shape[0]
+    roff = synth.offsets_for(nraw, L, dev)
+    keys = {}
+    eng = Engine(0)
+    try:
+        eng.load_targets_device(T.data_ptr(), toff.data_ptr(), NT)
+        order, ustart = eng.sort_unique_reads_arrays(raw.data_ptr(), roff.data_ptr(), nraw, True)
+        U = len(ustart) - 1
+        R = raw[torch.from_numpy(order[ustart[:-1]].astype(np.int64)).to(dev)]
+        del raw, roff, order, ustart
+        for path in ("context", "two-kernel"):
+            if path == "two-kernel":
+                monkeypatch.setenv("MUSC_NO_X_CONTEXT", "1")
+            n_all = eng.match_device(cfg, apply_mmtol=False)
+            st = eng.stats()
+            _log("cfg3 + X in the database, %s path (index kind %d): %d reads -> %d accepted tuples, device %.2f ms"
+                 % (path, st["index_kind"], U, n_all, st["ms_total"]))
+            assert st["index_kind"] == (1 if path == "context" else 0) and st["n_overflow_blocks"] == 0 and n_all > 0.5 * U
+            h32 = torch.empty((n_all, 4), dtype=torch.int32, device=dev)
+            eng.hits_to(h32.data_ptr(), n_all, True)
+            h = h32.to(torch.int64)
+            del h32
+            assert bool((h[:, 0] < U).all()) and bool((h[:, 1] < NT).all()) and bool((h[:, 3] <= budget).all())
+            if path == "context":
+                assert _hamming_ok(T.reshape(-1), TL, R, h, L), "nmiss is not the Hamming distance (X of the target = mismatch)"
+                # the X matter: some accepted placements cover one
+                ar = torch.arange(L, device=dev)
+                sub = h[:2_000_000]
+                covers = (T.reshape(-1)[(sub[:, 1] * TL + sub[:, 2])[:, None] + ar[None, :]] == ord("X")).any(dim=1)
+                assert int(covers.sum()) > 1000
+                del sub, covers
+            k = torch.sort((h[:, 0] << 36) | (h[:, 1] << 12) | (h[:, 2] << 2) | h[:, 3]).values
+            assert bool((k[1:] >> 2 != k[:-1] >> 2).all()), "the union over windows is not a set"
+            keys[path] = k
+            del h
+        assert keys["context"].shape == keys["two-kernel"].shape and bool((keys["context"] == keys["two-kernel"]).all()), \
+            "the two paths disagree on a database with X"
+        keys.clear()
+        # a sample against the literal oracle (context path)
+        monkeypatch.delenv("MUSC_NO_X_CONTEXT")
+        nt, ns = 50_000, 400_000
+        Rs = R[:: max(1, U // ns)][:ns].contiguous()
+        ns = Rs.shape[0]
+        rbuf = np.concatenate([Rs.reshape(-1).cpu().numpy(), np.zeros(8, np.uint8)])
+        gbuf = np.concatenate([T[:nt].reshape(-1).cpu().numpy(), np.zeros(8, np.uint8)])
+        rso = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
+        gso = np.arange(nt + 1, dtype=np.uint64) * np.uint64(TL)
+    finally:
+        eng.close()
+    del R, T, Rs
+    torch.cuda.empty_cache()
+
+    class OC:
+        Windows = list(wl.windows); WindowWidth = wl.window_width; PMatch = wl.pmatch
+        MinDinuc = wl.min_dinuc; MaxReadLength = L; MaxMatches = wl.max_matches; MatchMode = wl.match_mode
+    exp, _, _ = literal.match_arrays(rbuf, rso, gbuf, gso, literal.make_params(OC, bloom_size=200_000_000, num_hash=20, nthreads=16))
+    assert len(exp) > 0.02 * ns
+    with Engine(0) as e2:
+        e2.load_targets_arrays(gbuf, gso)
+        e2.load_reads_arrays(rbuf, rso)
+        got = sorted_hits(e2.match(cfg, apply_mmtol=False))
+        assert e2.stats()["index_kind"] == 1 and e2.stats()["n_overflow_blocks"] == 0
+        assert got.shape == exp.shape and (got == exp).all(), "GPU tuples differ from the literal oracle on the sample"
+    _log("cfg3 + X in the database: sample of %d reads x %d targets: %d tuples equal the literal oracle's" % (ns, nt, len(exp)))
