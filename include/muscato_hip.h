@@ -156,10 +156,12 @@ int musc_db_build_index(musc_ctx* ctx, int32_t window_width);
 /* The same for a whole parameter block: builds the index musc_match* will pick for `params` and
  * reads of at most max_read_len bases (0 = params->max_read_length) -- context buckets (128-byte
  * buckets that carry each placement's 120 surrounding target bases, so that screen and confirm
- * are one kernel and no target gather is needed; see kernels_match.hpp) when the run fits them,
- * the 64-byte-bucket index of musc_db_build_index otherwise.  musc_match* does this lazily;
+ * are one kernel and no target gather is needed, or 200 bases for two placements per bucket; see
+ * kernels_match.hpp) when the run fits them -- a database with X included: its entries whose
+ * context holds an X are flagged and compared as cmd/muscato_confirm/main.go:151-159 does -- the
+ * window-start-bucket index of musc_db_build_index otherwise.  musc_match* does this lazily;
  * calling it first only moves the one-off cost out of the first match.  MUSC_INDEX=classic in
- * the environment forces the 64-byte-bucket index. */
+ * the environment forces the window-start buckets, MUSC_NO_X_CONTEXT=1 only for runs with X. */
 int musc_db_build_index_for(musc_ctx* ctx, const musc_params* params, int32_t max_read_len);
 
 /* ---- reads: replaces reading reads_sorted.txt.sz (cmd/muscato_screen/main.go:120-191,
