@@ -127,12 +127,25 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   __shared__ uint8_t s_own[NWAVE][WT];                    //                   item -> window * 64 + read slot
   __shared__ uint16_t s_nm[CONF_NM];
 
-  // the run's parameters: scalars for the whole kernel
-  const int ww = mp->ww, CL = mp->CL, min_dinuc = mp->min_dinuc, direct = mp->direct, bits = mp->bits;
+  // the run's parameters: scalars for the whole kernel -- or, in a build specialised for one geometry
+  // (-DMUSC_SPEC_WW=15 -DMUSC_SPEC_CL=20 -DMUSC_SPEC_L=100 -DMUSC_SPEC_MIND=5 "-DMUSC_SPEC_WINS=0,20": a direct table,
+  // W windows at those starts), compile-time constants: the mask tables become immediates, the image shift a
+  // constant, and a third of the scalar instructions and of the spilled scalars go away
+#ifdef MUSC_SPEC_WW
+  constexpr bool SPEC = true;
+  constexpr int S_WW = MUSC_SPEC_WW, S_CL = MUSC_SPEC_CL, S_L = MUSC_SPEC_L, S_MIND = MUSC_SPEC_MIND;
+  constexpr int S_WIN[CTX_MAX_W] = {MUSC_SPEC_WINS};
+#else
+  constexpr bool SPEC = false;
+  constexpr int S_WW = 0, S_CL = 0, S_L = 0, S_MIND = 0;
+  constexpr int S_WIN[CTX_MAX_W] = {0, 0, 0, 0};
+#endif
+  const int ww = SPEC ? S_WW : mp->ww, CL = SPEC ? S_CL : mp->CL, min_dinuc = SPEC ? S_MIND : mp->min_dinuc,
+            direct = SPEC ? 1 : mp->direct, bits = SPEC ? 2 * S_WW : mp->bits;
   const uint32_t q1zero = mp->q1zero_mask;
   int win[W];
 #pragma unroll
-  for (int k = 0; k < W; k++) win[k] = mp->win[k];
+  for (int k = 0; k < W; k++) win[k] = SPEC ? S_WIN[k] : mp->win[k];
   uint32_t* const s_sketch = s_dyn + 2 * NWAVE * WT * W;
   for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)mp->max_len ? nmiss_tab[t] : (uint16_t)0;
   if (block_mode) {
@@ -290,6 +303,24 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     uint32_t wm[W][NW];
   };
   auto win_tab = [&](uint32_t ul, int k, uint32_t sh, uint32_t len, WinTab& tb) __attribute__((always_inline)) {
+    if constexpr (SPEC) {
+      // everything but the length is known: the masks are constants (the length mask for tiles of S_L-base reads)
+      tb.need = (1u << k) - 1u;
+      const int shc = 2 * (S_CL - S_WIN[k < W ? k : 0]);
+#pragma unroll
+      for (int kk = 0; kk < W; kk++)
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+          tb.wm[kk][j] = kk <= k ? bit_range_mask(shc + 2 * S_WIN[kk] - 32 * j, shc + 2 * (S_WIN[kk] + S_WW) - 32 * j) : 0u;
+      if (ul == (uint32_t)S_L) {
+#pragma unroll
+        for (int j = 0; j < NW; j++) tb.lm[j] = 0x55555555u & bit_range_mask(shc - 32 * j, shc + 2 * S_L - 32 * j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NW; j++) tb.lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * (int)len - 32 * j);
+      }
+      return;
+    }
     tb.need = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp->need[k]);
 #pragma unroll
     for (int kk = 0; kk < W; kk++) {
@@ -366,6 +397,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   auto diff_word = [&](uint32_t x, uint32_t xmj, uint32_t tmj, uint32_t lmj) __attribute__((always_inline)) -> uint32_t {
     if constexpr (DBX) return ((((x | (x >> 1)) & ~(xmj & tmj)) | (xmj ^ tmj))) & lmj;
     else if constexpr (RX) return ((x | (x >> 1)) | xmj) & lmj;
+    else if constexpr (SPEC) return (x | (x >> 1)) & lmj;
     else return base_diff(x, lmj);
   };
   auto score = [&](bool live, int k, int q1, const uint32_t (&img)[NW], const WinTab& tb, const uint32_t (&xm)[NW], uint32_t gene, uint32_t jx,
@@ -387,7 +419,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       for (int j = 0; j < NW; j++) {
         // (lm has no bit in the high half of the last word, where the context keeps the distance to the target end)
         d[j] = diff_word(img[j] ^ c[j], xm[j], tm[j], tb.lm[j]);
-        nx = bcnt_add(d[j], nx);
+        if (!SPEC || tb.lm[j] != 0u) nx = bcnt_add(d[j], nx);  // (SPEC: a word the read does not reach is a constant zero)
       }
       uint32_t exact = valid & (z ? ~q1zero : 0xFFFFFFFFu);
 #pragma unroll
@@ -395,7 +427,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         if (kk > k || !((tb.need >> kk) & 1u)) continue;  // wave-uniform
         uint32_t acc = 0;
 #pragma unroll
-        for (int j = 0; j < NW; j++) acc = and_or_s(d[j], tb.wm[kk][j], acc);
+        for (int j = 0; j < NW; j++) {
+          if constexpr (SPEC) acc |= d[j] & tb.wm[kk][j];  // (constants: the words a window does not touch fold away)
+          else acc = and_or_s(d[j], tb.wm[kk][j], acc);
+        }
         if (acc) exact &= ~(1u << kk);
       }
       // the reference's confirm for window k accepts the pair (it counts towards that window-key
