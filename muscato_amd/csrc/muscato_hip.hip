@@ -161,7 +161,7 @@ struct musc_ctx {
   uint32_t* dbm2 = nullptr;  // null when the database holds no X (or an all-zero plane made for reads that do)
   bool db_has_x = false;     // the database holds an X
   bool reads_have_x = false; // some loaded read holds an X
-  // reads with X on context buckets (k_match_t<.., RX>): where each read's X are (k_read_xpos), and
+  // reads with X on context buckets (k_match_t<.., XM = 1 | 2>): where each read's X are (k_read_xpos), and
   // whether the reads in hand fit that form under a given mismatch budget (k_xpos_check), cached
   DevBuf<uint32_t> rdx;
   uint64_t rdx_epoch = ~0ull;
