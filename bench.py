@@ -127,12 +127,16 @@ def cpu_baseline(wl, cfg, targets_ascii, reads_ascii, eng_factory, n_raw_full, l
     log("cpu sample: %d reads x %d targets, %d threads: window %.2fs bloom %.2fs scan %.2fs "
         "candsort %.2fs confirm %.2fs (wall %.2fs); %d hits; gpu bit-exact on sample: %s"
         % (s, tp, nthr, t_win, t_bloom, t_scan, t_csort, t_conf, wall, len(exp), exact))
-    full = None
-    try:  # the same port timed on the whole cfg3 workload, once, through gpurun (profiles/cpu_full.py)
-        with open(os.path.join(ROOT, "profiles", "r02_cpu_full.json")) as f:
-            full = json.load(f).get(wl.name)
-    except Exception:
-        pass
+    full, full_src = None, None
+    for cand in ("r03_cpu_full.json", "r02_cpu_full.json"):  # the same port timed on the whole cfg3 workload, once per round, through gpurun (profiles/cpu_full.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                full = json.load(f).get(wl.name)
+            if full:
+                full_src = "profiles/" + cand
+                break
+        except Exception:
+            pass
     return {
         # `value` is a TIMING: the raw reads of the sample over the wall time of the port on it (the
         # sample is BASELINE cfg2's size).  The whole workload through the same port is timed once per
@@ -145,7 +149,7 @@ def cpu_baseline(wl, cfg, targets_ascii, reads_ascii, eng_factory, n_raw_full, l
                    "sort+confirm %.2fs)" % (s, s + s // 9, tp, T, nthr, wall, t_scan, t_win + t_bloom, t_csort + t_conf)),
         "sample_wall_s": wall, "extrapolated_full_reads_per_s": value,
         "extrapolation": "scan*%.0f + read terms*%.1f + pair terms*%.1f*%.0f = %.1fs" % (ft, fr, fr, ft, t_full),
-        "full_workload_measured": full, "full_workload_source": "profiles/r02_cpu_full.json" if full else None,
+        "full_workload_measured": full, "full_workload_source": full_src,
         "gpu_bit_exact_on_sample": exact, "sample_hits": int(len(exp)),
         "single_thread": single,
     }

@@ -3,7 +3,7 @@
 4e9-bit Bloom filter per window, full target scan, bytewise candidate sort, block merge-join,
 byte-wise cdiff) timed on a WHOLE bench workload, not a sample ("configs 2 and 3
 in full").  Run once per round through gpurun (the synthetic data is generated on the GPU, as
-bench.py does); the line goes to profiles/r02_cpu_full.json and bench.py quotes it beside its
+bench.py does); the line goes to profiles/r<round>_cpu_full.json and bench.py quotes the latest beside its
 bounded sample.
 
     python3 profiles/cpu_full.py cfg3 [threads]
