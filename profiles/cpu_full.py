@@ -6,7 +6,7 @@ in full").  Run once per round through gpurun (the synthetic data is generated o
 bench.py does); the line goes to profiles/r<round>_cpu_full.json and bench.py quotes the latest beside its
 bounded sample.
 
-    python3 profiles/cpu_full.py cfg3 [threads]
+    python3 profiles/cpu_full.py cfg3 [threads] [xdb]     (xdb: X in the database -> profiles/r<round>_cpu_full_xdb.json)
 """
 import json
 import os
@@ -29,7 +29,25 @@ def main():
     dev = torch.device("cuda", 0)
     seed = synth.SEED_BASE + sum(ord(c) for c in wl.seed_key)
     T = synth.gen_targets(wl, dev, seed)
-    R = synth.sort_reads(synth.gen_unique_reads(wl, T, dev, seed + 7919))
+    xdb = len(sys.argv) > 3 and sys.argv[3] == "xdb"
+    if xdb:  # 0.1 % of the database's bases X one by one, plus 20 000 runs of 40 X (N stretches)
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed + 99)
+        for s0 in range(0, wl.n_targets, 100_000):
+            blk = T[s0:s0 + 100_000]
+            blk[torch.rand(blk.shape, device=dev, generator=g) < 0.001] = ord("X")
+        starts = torch.randint(0, T.numel() - 64, (20_000,), device=dev, generator=g)
+        flat = T.reshape(-1)
+        for d in range(40):
+            flat[starts + d] = ord("X")
+    R = synth.gen_unique_reads(wl, T, dev, seed + 7919)
+    if xdb:  # the reads sampled over an X get a random base there
+        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        for s0 in range(0, R.shape[0], 1_000_000):
+            blk = R[s0:s0 + 1_000_000]
+            isx = blk == ord("X")
+            blk[isx] = acgt[torch.randint(0, 4, (int(isx.sum()),), device=dev, generator=g)]
+    R = synth.sort_reads(R)
     keep = torch.ones(R.shape[0], dtype=torch.bool, device=dev)
     keep[1:] = (R[1:] != R[:-1]).any(dim=1)
     R = R[keep]
@@ -62,11 +80,13 @@ def main():
         eng.load_reads_arrays(rbuf, roff)
         got = eng.match(cfg, apply_mmtol=False)
         gpu_ms = eng.stats()["ms_total"]
+        index_kind = eng.stats()["index_kind"]
     def keys(a):  # (read, gene, pos, nmiss) -> one sortable u64 (26 + 24 + 10 + 4 bits)
         a = a.astype(np.uint64)
         return np.sort((a[:, 0] << np.uint64(38)) | (a[:, 1] << np.uint64(14)) | (a[:, 2] << np.uint64(4)) | a[:, 3])
     equal = bool(got.shape == hits.shape and (keys(got) == keys(hits)).all())
-    print(json.dumps({wl.name: {
+    print(json.dumps({wl.name + (" + X in the database (0.1 % one by one, 20 000 runs of 40)" if xdb else ""): {
+        "gpu_index_kind": index_kind,
         "reads_per_s": wl.n_raw_reads / wall, "wall_s": wall, "cores": nthr, "kind": "port",
         "raw_reads": wl.n_raw_reads, "distinct_reads": int(U), "targets": int(NT),
         "stages_s": {"windows": t_win, "bloom": t_bloom, "scan": t_scan, "candidate_sort": t_csort, "confirm": t_conf},
