@@ -6,7 +6,7 @@ in full").  Run once per round through gpurun (the synthetic data is generated o
 bench.py does); the line goes to profiles/r<round>_cpu_full.json and bench.py quotes the latest beside its
 bounded sample.
 
-    python3 profiles/cpu_full.py cfg3 [threads] [xdb]     (xdb: X in the database -> profiles/r<round>_cpu_full_xdb.json)
+    python3 profiles/cpu_full.py cfg3 [threads] [xdb | xreads]     (X in the database / in the reads -> profiles/r<round>_cpu_full_xdb.json / _xreads.json)
 """
 import json
 import os
@@ -47,6 +47,13 @@ def main():
             blk = R[s0:s0 + 1_000_000]
             isx = blk == ord("X")
             blk[isx] = acgt[torch.randint(0, 4, (int(isx.sum()),), device=dev, generator=g)]
+    xreads = len(sys.argv) > 3 and sys.argv[3] == "xreads"
+    if xreads:  # 0.1 % of the read bases X (N in the FASTQ), the database without
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed + 199)
+        for s0 in range(0, R.shape[0], 1_000_000):
+            blk = R[s0:s0 + 1_000_000]
+            blk[torch.rand(blk.shape, device=dev, generator=g) < 0.001] = ord("X")
     R = synth.sort_reads(R)
     keep = torch.ones(R.shape[0], dtype=torch.bool, device=dev)
     keep[1:] = (R[1:] != R[:-1]).any(dim=1)
@@ -85,7 +92,7 @@ def main():
         a = a.astype(np.uint64)
         return np.sort((a[:, 0] << np.uint64(38)) | (a[:, 1] << np.uint64(14)) | (a[:, 2] << np.uint64(4)) | a[:, 3])
     equal = bool(got.shape == hits.shape and (keys(got) == keys(hits)).all())
-    print(json.dumps({wl.name + (" + X in the database (0.1 % one by one, 20 000 runs of 40)" if xdb else ""): {
+    print(json.dumps({wl.name + (" + X in the database (0.1 % one by one, 20 000 runs of 40)" if xdb else " + X in the reads (0.1 % of their bases)" if xreads else ""): {
         "gpu_index_kind": index_kind,
         "reads_per_s": wl.n_raw_reads / wall, "wall_s": wall, "cores": nthr, "kind": "port",
         "raw_reads": wl.n_raw_reads, "distinct_reads": int(U), "targets": int(NT),
