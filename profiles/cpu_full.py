@@ -72,10 +72,22 @@ def main():
         MinDinuc = wl.min_dinuc; MaxReadLength = wl.read_len; MaxMatches = wl.max_matches
         MatchMode = wl.match_mode
     print("[cpu_full] %s: %d distinct reads x %d targets on %d threads ..." % (wl.name, U, NT, nthr), file=sys.stderr, flush=True)
+    # (a sign of life once a minute: the port runs for minutes without a word, and the GPU box's
+    # supervisor takes a command that writes nothing for seven minutes to be hung)
+    import threading
+    done = threading.Event()
+
+    def heartbeat():
+        t_start = time.time()
+        while not done.wait(60.0):
+            print("[cpu_full] ... the port has been running for %.0f s" % (time.time() - t_start), file=sys.stderr, flush=True)
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
     t0 = time.time()
     hits, tim, cnt = literal.match_arrays(rbuf, roff, gbuf, goff,
                                           literal.make_params(OC, bloom_size=4_000_000_000, num_hash=20, nthreads=nthr))
     wall = time.time() - t0
+    done.set()
     t_win, t_bloom, t_scan, t_csort, t_conf = [float(x) for x in tim]
     print("[cpu_full] %.1fs; %d tuples; now the GPU path on the same arrays ..." % (wall, len(hits)), file=sys.stderr, flush=True)
     # the whole workload through the GPU path, tuple for tuple against the port (every accepted tuple, no MMTol)
