@@ -483,8 +483,9 @@ def main() -> int:
             # (1b) the same sized pass replayed as one hipGraph launch (MUSC_GRAPH=1, opt-in): what is
             # left of the host's share once the seven launches per batch are one
             os.environ["MUSC_GRAPH"] = "1"
+            eng.reload_env()  # (the knobs are read once per context; the next pass sizes itself again)
             try:
-                for _ in range(2):  # capture, first replay
+                for _ in range(3):  # sizing pass, capture, first replay
                     assert match() == n0
                 torch.cuda.synchronize()
                 dev_ms = 0.0
@@ -499,6 +500,8 @@ def main() -> int:
                                         "what": "MUSC_GRAPH=1: sized pass as one hipGraphLaunch + one stream sync"}
             finally:
                 os.environ.pop("MUSC_GRAPH", None)
+                eng.reload_env()
+                match()  # (sized again for the legs below)
 
         if not args.no_survey_scope and not args.unsorted and args.xrate == 0:
             # (2) SURVEY.md 8d's timer scope (reference wall: cmd/muscato/main.go:306-420, screen ->

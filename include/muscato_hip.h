@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MUSC_ABI_VERSION 2
+#define MUSC_ABI_VERSION 3
 #define MUSC_MAX_WINDOWS 16
 
 typedef struct musc_ctx musc_ctx;
@@ -99,9 +99,11 @@ typedef struct {
   uint32_t confirm_launches;
   uint32_t n_batches;
   float ms_screen;          /* HIP-event time of each kernel family, summed over batches:  */
-  float ms_scan;            /*   k_screen (index_kind 0) or k_match (1) | scan | (unused) |
+  float ms_scan;            /*   k_screen (index_kind 0) or k_match (1) | scan | (see match_variant) |
                              *   k_confirm (index_kind 0 only) | scan+k_compact            */
-  float ms_unused0;
+  uint32_t match_variant;   /* (ABI 3; the slot was an unused float) which fused kernel ran on context buckets:
+                             * 0 = none (two-kernel path), 1 = k_match (quad per probe), 2 = k_match_t, general
+                             * instance, 3 = k_match_t specialised for the run's geometry (SpecGeom<1>)        */
   float ms_confirm;
   float ms_select;
   float ms_total;           /* first launch to last completion on the context's stream  */
@@ -132,6 +134,10 @@ int musc_abi_version(void);
 int musc_init(int device_ordinal, musc_ctx** out);
 void musc_destroy(musc_ctx* ctx);
 const char* musc_last_error(musc_ctx* ctx); /* ctx may be NULL: error of a failed musc_init */
+/* The MUSC_* environment knobs (tests, A/B runs: MUSC_INDEX, MUSC_MATCH, MUSC_GRAPH ...) are read once, by
+ * musc_init; a pass never calls getenv.  This re-reads them for a live context (a test hook; the next pass sizes
+ * its buffers again).  The reference has no counterpart: its knobs are the Config fields. */
+int musc_reload_env(musc_ctx* ctx);
 
 /* ---- target database: replaces muscato_screen's scan of GeneFileName
  * (cmd/muscato_screen/main.go:408-452; gene number = sequence index). --------------------

@@ -42,7 +42,7 @@ class MuscStats(ctypes.Structure):
         ("n_hits", ctypes.c_uint64), ("n_overflow_blocks", ctypes.c_uint64),
         ("confirm_bytes", ctypes.c_uint64),
         ("confirm_launches", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),
-        ("ms_screen", ctypes.c_float), ("ms_scan", ctypes.c_float), ("ms_unused0", ctypes.c_float),
+        ("ms_screen", ctypes.c_float), ("ms_scan", ctypes.c_float), ("match_variant", ctypes.c_uint32),
         ("ms_confirm", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_total", ctypes.c_float),
         ("ms_index_build", ctypes.c_float), ("ms_read_prep", ctypes.c_float),
         ("n_descriptors", ctypes.c_uint64),
@@ -54,7 +54,7 @@ class MuscStats(ctypes.Structure):
 
 # every symbol include/muscato_hip.h declares
 SYMBOLS = [
-    "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error",
+    "musc_abi_version", "musc_init", "musc_destroy", "musc_last_error", "musc_reload_env",
     "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for",
     "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_load_packed32", "musc_reads_sort_unique",
     "musc_match_device", "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_free_hits",
@@ -96,6 +96,7 @@ def load() -> ctypes.CDLL:
     lib.musc_destroy.restype = None
     lib.musc_last_error.argtypes = [vp]
     lib.musc_last_error.restype = ctypes.c_char_p
+    lib.musc_reload_env.argtypes = [vp]
     lib.musc_db_load_ascii.argtypes = [vp, vp, vp, ctypes.c_uint32, ctypes.c_int]
     lib.musc_db_load_packed.argtypes = [vp, vp, vp, vp, ctypes.c_uint32]
     lib.musc_db_build_index.argtypes = [vp, i32]
@@ -122,7 +123,7 @@ def load() -> ctypes.CDLL:
                                 ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.musc_gather_rccl.argtypes = lib.musc_gather.argtypes
     lib.musc_rccl_probe.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
-    for name in ("musc_init", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for", "musc_db_build_index_for",
+    for name in ("musc_init", "musc_reload_env", "musc_db_load_ascii", "musc_db_load_packed", "musc_db_build_index", "musc_db_build_index_for", "musc_db_build_index_for",
                  "musc_reads_load_ascii", "musc_reads_load_packed", "musc_reads_load_packed32", "musc_reads_sort_unique", "musc_match_device",
                  "musc_hits_copy", "musc_hits_copy_packed", "musc_hits_copy_compact", "musc_hits_unpack", "musc_match", "musc_get_stats",
                  "musc_gather", "musc_gather_rccl", "musc_rccl_probe"):

@@ -178,6 +178,10 @@ class Engine:
             raise MuscatoError("%s failed (%d): %s" % (what, rc, self._lib.musc_last_error(self._h).decode()))
 
     # ---- database (gene number = index in the list = line index of GeneFileName)
+    def reload_env(self) -> None:
+        """Re-read the MUSC_* knobs (the library reads them once, at musc_init)."""
+        self._check(self._lib.musc_reload_env(self._h), "musc_reload_env")
+
     def load_targets(self, seqs: Sequence[bytes]) -> None:
         buf, off = concat(seqs)
         self.load_targets_arrays(buf, off)

@@ -13,7 +13,7 @@ OBJ = os.path.join(HERE, "build")
 # one translation unit for the host side and most kernels, and one per record stride for k_match_t
 # (kernels_match_lane_inst.hpp): they compile side by side
 SOURCES = [os.path.join(CSRC, f) for f in ("muscato_hip.hip", "match_lane_rw4.hip", "match_lane_rw8.hip", "match_lane_rw12.hip",
-                                           "match_lane_rw8w.hip", "match_lane_rw12w.hip", "match_lane_rw16w.hip")]
+                                           "match_lane_rw8w.hip", "match_lane_rw12w.hip", "match_lane_rw16w.hip", "match_lane_rw8s.hip")]
 HEADERS = [os.path.join(os.path.dirname(HERE), "include", "muscato_hip.h")] + \
     [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
 LANE_ONLY = os.path.join(CSRC, "kernels_match_lane.hpp")  # k_match_t's definition: muscato_hip.hip sees its declaration only
@@ -92,7 +92,7 @@ def variant(name: str, defines) -> str:
     os.makedirs(out_dir, exist_ok=True)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         # (-DMAIN... flags go to the main unit, everything else to the k_match_t units)
-        main_defs = [d[len("-DMAIN_"):].join(["-D", ""]) if False else "-D" + d[len("-DMAIN_"):] for d in defines if d.startswith("-DMAIN_")]
+        main_defs = ["-D" + d[len("-DMAIN_"):] for d in defines if d.startswith("-DMAIN_")]
         lane_defs = [d for d in defines if not d.startswith("-DMAIN_")]
         objs = list(ex.map(lambda s: _compile(s, False, False, lane_defs if "match_lane" in s else main_defs,
                                               "." + name if ("match_lane" in s and lane_defs) or ("match_lane" not in s and main_defs) else ""), SOURCES))

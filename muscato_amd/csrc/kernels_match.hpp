@@ -269,7 +269,7 @@ MUSC_KERNEL void k_ctx_ovf_set(CtxBucket* __restrict__ T, uint64_t nb, const uin
 struct MatchParams {
   int32_t W, ww, min_dinuc, bits, direct, mmtol, apply_mmtol, max_len, CL;
   uint32_t q1zero_mask;
-  int32_t dbg;  // experiments only (MUSC_DEBUG_MATCH): 1 skip the comparisons, 2 skip the bucket loads, 4 skip phase C
+  int32_t reserved0;  // (was a run-time experiment knob; experiments are compile-time now: -DMUSC_MATCH_DBG=n)
   int32_t win[CTX_MAX_W];
   // a database with X (k_match_t<.., XM = 2>): where a target starts and the mask plane, read for flagged entries only
   const uint64_t* seq_off;
@@ -548,7 +548,13 @@ __global__ __launch_bounds__(TILE, W2 ? MATCH_WAVES : 2) void k_match(const uint
   const int W = mp->W, ww = mp->ww, CL = mp->CL;
   const int win0 = mp->win[0], win1 = mp->win[1];
   const uint32_t q1zero = mp->q1zero_mask;
-  const int dbg = mp->dbg;
+  // timing experiments only, compile-time (-DMUSC_MATCH_DBG=n: 1 skip the comparisons, 2 skip the bucket loads, 4 skip phase C;
+  // wrong tuples): the shipped library cannot be talked into them by an environment variable
+#ifdef MUSC_MATCH_DBG
+  constexpr int dbg = MUSC_MATCH_DBG;
+#else
+  constexpr int dbg = 0;
+#endif
   uint32_t* const s_sketch = s_dyn + NWAVE * WT * W;
   for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)mp->max_len ? nmiss_tab[t] : (uint16_t)0;
   if (block_mode == 1)

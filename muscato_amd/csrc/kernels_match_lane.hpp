@@ -86,7 +86,7 @@ DEV void read_image_n(const Rec<RW>& rec, uint32_t sh, uint32_t (&img)[NW]) {
 }
 
 
-template <int RW, int W, int XM, bool WIDE>
+template <int RW, int W, int XM, bool WIDE, int SG>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
@@ -127,19 +127,26 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   __shared__ uint8_t s_own[NWAVE][WT];                    //                   item -> window * 64 + read slot
   __shared__ uint16_t s_nm[CONF_NM];
 
-  // the run's parameters: scalars for the whole kernel -- or, in a build specialised for one geometry
-  // (-DMUSC_SPEC_WW=15 -DMUSC_SPEC_CL=20 -DMUSC_SPEC_L=100 -DMUSC_SPEC_MIND=5 "-DMUSC_SPEC_WINS=0,20": a direct table,
-  // W windows at those starts), compile-time constants: the mask tables become immediates, the image shift a
-  // constant, and a third of the scalar instructions and of the spilled scalars go away
-#ifdef MUSC_SPEC_WW
-  constexpr bool SPEC = true;
-  constexpr int S_WW = MUSC_SPEC_WW, S_CL = MUSC_SPEC_CL, S_L = MUSC_SPEC_L, S_MIND = MUSC_SPEC_MIND;
-  constexpr int S_WIN[CTX_MAX_W] = {MUSC_SPEC_WINS};
-#else
-  constexpr bool SPEC = false;
-  constexpr int S_WW = 0, S_CL = 0, S_L = 0, S_MIND = 0;
-  constexpr int S_WIN[CTX_MAX_W] = {0, 0, 0, 0};
-#endif
+  // the run's parameters: scalars for the whole kernel -- or, in an instance specialised for one geometry
+  // (SpecGeom<SG>, kernels_match_lane_inst.hpp), compile-time constants: the mask tables become immediates, the
+  // image shift a constant, and a third of the scalar instructions and of the spilled scalars go away
+  typedef SpecGeom<SG> SGm;
+  constexpr bool SPEC = SGm::on;
+  static_assert(!SPEC || (SGm::nwin == W && !WIDE && XM == 0 && SGm::ww <= 15), "a specialised instance is built for its geometry's window count, 120-base buckets, no X, a direct table of one-word keys");
+  constexpr int S_WW = SGm::ww, S_CL = SGm::CL, S_L = SGm::L, S_MIND = SGm::min_dinuc;
+  constexpr int S_WIN[CTX_MAX_W] = {SGm::win[0], SGm::win[1], SGm::win[2], SGm::win[3]};
+  if constexpr (SPEC) {
+    // the host compared the geometry before it chose this instance (spec_geom_matches); a mismatch here is a bug
+    // there: refuse -- no table access, no tuple -- and say so (flag 8 of the pass-level flag word).  r03's fault
+    // (gpurun_out/var.err) was a development build of this kind let loose on cfg2's hashed table.
+    bool same = mp->ww == S_WW && mp->CL == S_CL && mp->min_dinuc == S_MIND && mp->direct == 1 && mp->bits == 2 * S_WW && mp->W == W;
+#pragma unroll
+    for (int k = 0; k < W; k++) same = same && mp->win[k] == S_WIN[k] && mp->need[k] == (1u << k) - 1u;
+    if (!same) {
+      if (threadIdx.x == 0) atomicOr(&counters[3], 8ull);
+      return;
+    }
+  }
   const int ww = SPEC ? S_WW : mp->ww, CL = SPEC ? S_CL : mp->CL, min_dinuc = SPEC ? S_MIND : mp->min_dinuc,
             direct = SPEC ? 1 : mp->direct, bits = SPEC ? 2 * S_WW : mp->bits;
   const uint32_t q1zero = mp->q1zero_mask;
@@ -170,6 +177,9 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   const uint32_t mmtol = (uint32_t)mp->mmtol;
   const bool apply = mp->apply_mmtol != 0;
 
+  // a lane fetches its own read's record (tried in r04: the tile's records as RW / 4 loads of 1 KB contiguous,
+  // transposed through s_rec -- 1.105 ms per cfg3 launch against 1.08-1.09 for this form: the lines are shared
+  // by neighbouring lanes of one load anyway, and the transposition costs a second LDS round trip per tile)
   auto fetch = [&](uint32_t wt, Rec<RW>& rec) __attribute__((always_inline)) {
     const uint32_t i = wt * WT + (opaque(threadIdx.x) & 63);
     rec.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);
@@ -233,28 +243,31 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     nvalid += __popc(valid);
     return valid;
   };
-  // the bucket loads of one window: four steps of 16 probes, a quad of lanes per probe (32 bytes per
-  // lane).  bbk = this lane's read's bucket for that window; a quad gets its probe's bucket from the
-  // lane that owns the read (ds_bpermute: the LDS crossbar, no memory), all four steps before the
-  // first address is formed -- one round trip, not four.
+  // the bucket loads of one window: eight loads of EIGHT WHOLE LINES each -- eight lanes per line, 16 contiguous
+  // bytes per lane, so a load instruction asks for eight full 128-byte lines (r04: the quad-per-line shape of r03,
+  // 32 bytes per lane in two loads, made every line two strided half-requests and cost 9 % of the launch;
+  // profiles/r04_ub_dma_lines.txt has the bare access patterns side by side).  bbk = this lane's read's bucket
+  // for that window; the eight lanes of a line get it from the lane that owns the read (ds_bpermute: the LDS
+  // crossbar, no memory), all eight before the first address is formed -- one round trip, not eight.  Lane l of
+  // load i takes the chunk that belongs at slot l & 7 of line 8 i + (l >> 3) in the swizzled line buffer, so the
+  // arrival writes 1 KB contiguously per load.  A probe that takes no part fetches bucket 0 (always there); its
+  // owner ignores the line (the header's count is masked).
   auto issue_window = [&](uint32_t bbk, uint4 (&a)[4], uint4 (&b2)[4]) __attribute__((always_inline)) {
-    const uint32_t lane = opaque(threadIdx.x) & 63, part = lane & 3;
-    uint32_t b[4];
+    const uint32_t lane = opaque(threadIdx.x) & 63;
+    uint32_t bq[8];
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) b[rr] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rr * 16 + (lane >> 2)) * 4), (int)bbk);
+    for (int i = 0; i < 8; i++) bq[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((i * 8 + (lane >> 3)) * 4), (int)bbk);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      a[rr].x = 0;  // a probe that takes no part reads as an empty bucket (count 0 in the quad's first lane)
+    for (int i = 0; i < 8; i++) {
+      const uint32_t pl = (uint32_t)i * 8u + (lane >> 3);
+      const uint32_t c = (lane & 7u) ^ (((pl >> 1) & 7u) ^ (pl & 1u));
 #ifdef MUSC_LANE_DBG
-      if (b[rr] != WB_NONE && !(MUSC_LANE_DBG & 2)) {
-#else
-      if (b[rr] != WB_NONE) {
+      if (MUSC_LANE_DBG & 2) continue;
 #endif
-        const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + b[rr]) + 2 * part;
-        const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
-        a[rr] = make_uint4(x.x, x.y, x.z, x.w);
-        b2[rr] = make_uint4(y.x, y.y, y.z, y.w);
-      }
+      const u32x4_v* p = reinterpret_cast<const u32x4_v*>(T + (bq[i] != WB_NONE ? bq[i] : 0u)) + c;
+      const u32x4_v x = __builtin_nontemporal_load(p);
+      if (i < 4) a[i] = make_uint4(x.x, x.y, x.z, x.w);
+      else b2[i - 4] = make_uint4(x.x, x.y, x.z, x.w);
     }
   };
 
@@ -479,6 +492,17 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
 
   // phase A of a wave-tile plus what its lanes keep of it: the meta word (length | budget << 17 | valid
   // windows << 24); the record itself goes to s_rec[p]
+  // the record of read slot `seg` of the wave-tile whose records are in s_rec[p]
+  auto rec_of = [&](uint32_t p, uint32_t seg, Rec<RW>& rec) __attribute__((always_inline)) {
+    const uint32_t wid = opaque(threadIdx.x) >> 6;
+    const uint4* src = reinterpret_cast<const uint4*>(&s_rec[p][wid][seg * RW]);
+#pragma unroll
+    for (int q = 0; q < RW / 4; q++) {
+      const uint4 v = src[q];
+      rec.w[4 * q] = v.x; rec.w[4 * q + 1] = v.y; rec.w[4 * q + 2] = v.z; rec.w[4 * q + 3] = v.w;
+    }
+  };
+
   auto phase_a_all = [&](uint32_t wt, uint32_t p, const Rec<RW>& rec, uint32_t& meta, uint32_t& xw, uint32_t (&bb)[W]) __attribute__((always_inline)) {
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6;
@@ -489,16 +513,6 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     uint4* dst = reinterpret_cast<uint4*>(&s_rec[p][wid][lane * RW]);
 #pragma unroll
     for (int q = 0; q < RW / 4; q++) dst[q] = make_uint4(rec.w[4 * q], rec.w[4 * q + 1], rec.w[4 * q + 2], rec.w[4 * q + 3]);
-  };
-  // the record of read slot `seg` of the wave-tile whose records are in s_rec[p]
-  auto rec_of = [&](uint32_t p, uint32_t seg, Rec<RW>& rec) __attribute__((always_inline)) {
-    const uint32_t wid = opaque(threadIdx.x) >> 6;
-    const uint4* src = reinterpret_cast<const uint4*>(&s_rec[p][wid][seg * RW]);
-#pragma unroll
-    for (int q = 0; q < RW / 4; q++) {
-      const uint4 v = src[q];
-      rec.w[4 * q] = v.x; rec.w[4 * q + 1] = v.y; rec.w[4 * q + 2] = v.z; rec.w[4 * q + 3] = v.w;
-    }
   };
 
   if (gw < nwt) {
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   while (wt < nwt || have_prev) {
     const bool have_cur = wt < nwt;
     const uint32_t tid = opaque(threadIdx.x);
-    const uint32_t lane = tid & 63, wid = tid >> 6, part = lane & 3;
+    const uint32_t lane = tid & 63, wid = tid >> 6;
     uint32_t* const cnt_l = s_cb[wid];
     uint32_t* const base_l = s_cb[wid] + WT;
     uint4* const line_l = s_line[wid];
@@ -880,16 +894,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint32_t sh = 2u * (uint32_t)(CL - q1);
         WinTab tb;  // (its scalar loads are in flight while the wave waits for the window's lines)
         win_tab(ulen, k, sh, (uint32_t)rlen, tb);
-        // ---- arrival: the quads write the lines they fetched into the line buffer (swizzled) ...
+        // ---- arrival: every load's 1 KB goes into the line buffer as it came (the swizzle is in the load's choice of chunk) ...
         {
-          const uint32_t q = lane >> 2;
-          const uint32_t sw = ((q >> 1) & 7u) ^ (q & 1u);
-          const uint32_t wb0 = q * 8u + ((2u * part) ^ sw);  // in units of 16 bytes; the line's second half: ^ 1
 #pragma unroll
-          for (int rr = 0; rr < 4; rr++) {
-            line_l[rr * 128 + wb0] = va[rr];
-            line_l[rr * 128 + (wb0 ^ 1u)] = vb[rr];
-          }
+          for (int i = 0; i < 8; i++) line_l[i * 64 + lane] = i < 4 ? va[i] : vb[i - 4];
         }
         PF(0)
         // ---- ... and with nothing left in flight: the loads of prev's overflow entries (used after the
@@ -915,7 +923,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         // buffer stays as it is until the next arrival)
         const uint32_t rb = lane * 8u + (((lane >> 1) & 7u) ^ (lane & 1u));
         const uint4 h0 = line_l[rb], h1 = line_l[rb ^ 1u];
-        const uint32_t cnt = h0.x;
+        const uint32_t cnt = bb_cur[k] != WB_NONE ? h0.x : 0u;  // (a probe that takes no part fetched bucket 0)
         ncand += cnt;
         oc[k] = cnt > (uint32_t)NIN ? cnt - (uint32_t)NIN : 0u;
         ovf[k] = h0.y;

@@ -18,8 +18,16 @@ struct PathParams {
   uint32_t q1zero_mask;  // windows whose start is 0 (the pos-0 path of processSeq)
   int32_t wide;          // database >= 2^32 bases: 40-bit positions (gene < 2^24)
   int32_t max_len;       // longest read loaded
-  int32_t dbg;           // experiments only (MUSC_DEBUG_SCREEN): 1 skip entry tests, 2 skip bucket loads, 4 skip desc writes, 8 no two-window descriptors
+  int32_t reserved0;     // (was a run-time experiment knob; experiments are compile-time now: -DMUSC_SCREEN_DBG=n)
 };
+
+// timing experiments only, compile-time (-DMUSC_SCREEN_DBG=n: 1 skip entry tests, 2 skip bucket loads, 4 skip descriptor
+// writes, 8 no two-window descriptors, 256 skip the bucket phase; wrong tuples)
+#ifdef MUSC_SCREEN_DBG
+#define SCREEN_DBG (MUSC_SCREEN_DBG)
+#else
+#define SCREEN_DBG 0
+#endif
 
 // A read record: RW u32 words, bases (2 bits each) in words 0..RW-2, length in word RW-1.
 // RW > 0: the whole record sits in registers after two (or more) 16-byte loads -- the
@@ -235,7 +243,8 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
                                                  uint32_t* __restrict__ wb,
                                                  uint32_t* __restrict__ tbase,
                                                  uint32_t* __restrict__ tcount,
-                                                 unsigned long long* __restrict__ counters) {
+                                                 unsigned long long* __restrict__ counters,
+                                                 unsigned long long* __restrict__ pass_flags) {
   // Phase A: a thread per read gates the read's windows and names their buckets.
   // Phase B: the 64-byte buckets are fetched by quads of lanes (16 bytes each: one wave
   // instruction brings 16 whole buckets, every line is requested once) and stay in registers:
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
       if (below == 0 && ok) first = atomicAdd(&s_tilecnt, (uint32_t)__popcll(vote));  // the first voter
       first = __builtin_amdgcn_readlane(first, __builtin_ctzll(vote));
       const uint32_t slot = first + below;
-      if (ok && slot < room && !(pp.dbg & 4)) {
+      if (ok && slot < room && !(SCREEN_DBG & 4)) {
         const uint32_t left = ent.z & 0xFFFFu;
         const uint32_t pos_ok = left < 65535u ? 1u : 0u;
         // global offset of the placement (40 bits in wide mode: the high byte rides in x)
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
         // compared on their own; k_confirm's first-window rule keeps the tuple set the same.)
         const uint4* __restrict__ TL = reinterpret_cast<const uint4*>(T);
 #pragma unroll 1
-        for (int h = 0; h < ((pp.dbg & 256) ? 0 : 16 / SCR_LROUNDS); h++) {
+        for (int h = 0; h < ((SCREEN_DBG & 256) ? 0 : 16 / SCR_LROUNDS); h++) {
           const uint32_t tidb = opaque(threadIdx.x);
           const uint32_t lane = tidb & 63, wid = tidb >> 6, part = lane & 7;
           uint4 v[SCR_LROUNDS];
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
           for (int rr = 0; rr < SCR_LROUNDS; rr++) {
             const uint32_t b = s_bb[wid * 128 + (SCR_LROUNDS * h + rr) * 8 + (lane >> 3)];
             v[rr] = make_uint4(0, 0, 0, 0);
-            if (b != WB_NONE && !(pp.dbg & 2)) {
+            if (b != WB_NONE && !(SCREEN_DBG & 2)) {
               const u32x4_v t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(TL + (uint64_t)b * 8u) + part);
               v[rr] = make_uint4(t.x, t.y, t.z, t.w);
             }
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
             }
             const int k = k0 + (int)(probe & 1u), q1 = (probe & 1u) ? q1b : q1a;
             uint32_t z = 0;
-            bool ok = part >= 1 && part - 1 < cnt && !(pp.dbg & 1);
+            bool ok = part >= 1 && part - 1 < cnt && !(SCREEN_DBG & 1);
             if (ok) ok = screen_entry_ok(v[rr], q1, pp.ww, s_rfl[probe], s_lenbud[probe], &z);
             append(ok, v[rr], probe, k, q1, z, false);
           }
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
       } else {
       // ---- phase B: buckets by quads; a wave fetches the 128 probes of its own 64 reads
 #pragma unroll 1
-      for (int h = 0; h < ((pp.dbg & 256) ? 0 : 8 / SCR_ROUNDS); h++) {
+      for (int h = 0; h < ((SCREEN_DBG & 256) ? 0 : 8 / SCR_ROUNDS); h++) {
         const uint32_t tidb = opaque(threadIdx.x);
         const uint32_t lane = tidb & 63, wid = tidb >> 6;
         uint4 v[SCR_ROUNDS];
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
         for (int rr = 0; rr < SCR_ROUNDS; rr++) {
           const uint32_t b = s_bb[wid * 128 + (SCR_ROUNDS * h + rr) * 16 + (lane >> 2)];
           v[rr] = make_uint4(0, 0, 0, 0);
-          if (b != WB_NONE && !(pp.dbg & 2)) {
+          if (b != WB_NONE && !(SCREEN_DBG & 2)) {
             // non-temporal: a bucket is used once (measured: random 64-B fetches run 12 % faster)
             const u32x4_v t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(T + b) + (lane & 3));
             v[rr] = make_uint4(t.x, t.y, t.z, t.w);
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
           }
           const int k = k0 + (int)(probe & 1u), q1 = (probe & 1u) ? q1b : q1a;
           uint32_t z = 0;
-          bool ok = part >= 1 && part - 1 < cnt && !(pp.dbg & 1);
+          bool ok = part >= 1 && part - 1 < cnt && !(SCREEN_DBG & 1);
           if (ok) ok = screen_entry_ok(v[rr], q1, pp.ww, s_rfl[probe], s_lenbud[probe], &z);
           // The read's two windows sit in neighbouring quads.  When both hold a surviving entry
           // for the same placement, one descriptor stands for both (k_confirm compares the
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
           }
           MUSC_QROT(0x39) MUSC_QROT(0x4E) MUSC_QROT(0x93)  // the partner quad's other three parts
 #undef MUSC_QROT
-          if (!ok || (pp.dbg & 8)) same = 0;
+          if (!ok || (SCREEN_DBG & 8)) same = 0;
           const bool two = same && !odd;
           if (same && odd) ok = false;
           ntwo += two;
@@ -467,11 +476,11 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
       lds_barrier();
       // ---- phase C: the chunk's overflow entries as one flat list, in (read, window, entry) order
       const uint32_t tidc = opaque(threadIdx.x);
-      if (pp.dbg & 256) continue;
+      if (SCREEN_DBG & 256) continue;
       const uint32_t oc0 = s_oc[2 * tidc], oc1 = s_oc[2 * tidc + 1];
       uint32_t total = 0;
       const uint32_t pre = wg_scan(oc0 + oc1, &total);
-      if (total != 0 && !(pp.dbg & 1)) {  // uniform
+      if (total != 0 && !(SCREEN_DBG & 1)) {  // uniform
         s_pref[2 * tidc] = pre;
         s_pref[2 * tidc + 1] = pre + oc0;
         if (tidc == TILE - 1) s_pref[SCR_PROBES] = total;
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(TILE, (ONE && !MASK) ? 8 : SCR_WAVES) void k_screen
   if (threadIdx.x == 0) {
     atomicAdd(&counters[4], (unsigned long long)used);
     atomicMax(&counters[7], (unsigned long long)used);
-    if (used > region) atomicOr(&counters[3 - 8], 1ull);  // pass-level flag: descriptor space ran out
+    if (used > region) atomicOr(pass_flags, 1ull);  // pass-level flag: descriptor space ran out
   }
 }
 

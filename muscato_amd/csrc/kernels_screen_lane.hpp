@@ -38,7 +38,8 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
                                                              uint4* __restrict__ desc, uint64_t desc_cap,
                                                              uint32_t* __restrict__ rvalid, uint32_t* __restrict__ wb,
                                                              uint32_t* __restrict__ tbase, uint32_t* __restrict__ tcount,
-                                                             unsigned long long* __restrict__ counters) {
+                                                             unsigned long long* __restrict__ counters,
+                                                             unsigned long long* __restrict__ pass_flags) {
   const PathParams& pp = *ppp;
   __shared__ uint4 s_line[64 * 8];      // 64 lines (a window's buckets, or overflow lines), swizzled
   __shared__ uint32_t s_rfl[64];        // the window's probes: the read's own 8+8 flanking bases
@@ -59,36 +60,30 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
   const uint32_t lane = opaque(threadIdx.x) & 63;
   const uint32_t rb = lane * 8u + (((lane >> 1) & 7u) ^ (lane & 1u));  // this lane's line in the buffer, chunk c at rb ^ c
 
-  // the loads of 64 lines, a quad of lanes per line (32 bytes per lane); lid = this lane's line (an
-  // index into `base` in lines of eight uint4, or WB_NONE): a quad gets its line's number from the
-  // lane that names it (ds_bpermute), all four steps before the first address is formed
+  // the loads of 64 lines: eight loads of EIGHT WHOLE LINES each (eight lanes per line, 16 contiguous bytes per
+  // lane: the access shape of k_match_t's issue_window -- a quad per line with 32 bytes per lane in two loads made
+  // every line two strided half-requests).  lid = this lane's line (an index into `base` in lines of eight uint4,
+  // or WB_NONE: the lane that asked then sees line 0 of `base` and must ignore it); the eight lanes of a line get
+  // its number from the lane that names it (ds_bpermute), all eight before the first address is formed.  Lane l
+  // of load i takes the chunk that belongs at slot l & 7 of line 8 i + (l >> 3) in the swizzled line buffer
+  // (chunk c of line p at slot c ^ ((p >> 1) & 7) ^ (p & 1)), so land64 writes 1 KB contiguously per load.
   auto issue64 = [&](const uint4* __restrict__ base, uint32_t lid, uint4 (&a)[4], uint4 (&b2)[4]) __attribute__((always_inline)) {
-    const uint32_t part = lane & 3;
-    uint32_t b[4];
+    uint32_t bq[8];
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) b[rr] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rr * 16 + (lane >> 2)) * 4), (int)lid);
+    for (int i = 0; i < 8; i++) bq[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((i * 8 + (lane >> 3)) * 4), (int)lid);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      a[rr].x = 0;  // a line nobody asked for reads as an empty bucket (count 0 in the quad's first lane)
-      if (b[rr] != WB_NONE) {
-        const u32x4_v* p = reinterpret_cast<const u32x4_v*>(base + (uint64_t)b[rr] * 8u) + 2 * part;
-        const u32x4_v x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1);
-        a[rr] = make_uint4(x.x, x.y, x.z, x.w);
-        b2[rr] = make_uint4(y.x, y.y, y.z, y.w);
-      }
+    for (int i = 0; i < 8; i++) {
+      const uint32_t pl = (uint32_t)i * 8u + (lane >> 3);
+      const uint32_t c = (lane & 7u) ^ (((pl >> 1) & 7u) ^ (pl & 1u));
+      const u32x4_v* p = reinterpret_cast<const u32x4_v*>(base + (uint64_t)(bq[i] != WB_NONE ? bq[i] : 0u) * 8u) + c;
+      const u32x4_v x = __builtin_nontemporal_load(p);
+      if (i < 4) a[i] = make_uint4(x.x, x.y, x.z, x.w);
+      else b2[i - 4] = make_uint4(x.x, x.y, x.z, x.w);
     }
   };
-  // the quads write the lines they fetched into the line buffer: chunk c of line p at slot
-  // c ^ ((p >> 1) & 7) ^ (p & 1) (kernels_match_lane.hpp)
   auto land64 = [&](const uint4 (&a)[4], const uint4 (&b2)[4]) __attribute__((always_inline)) {
-    const uint32_t part = lane & 3, q = lane >> 2;
-    const uint32_t sw = ((q >> 1) & 7u) ^ (q & 1u);
-    const uint32_t wb0 = q * 8u + ((2u * part) ^ sw);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      s_line[rr * 128 + wb0] = a[rr];
-      s_line[rr * 128 + (wb0 ^ 1u)] = b2[rr];
-    }
+    for (int i = 0; i < 8; i++) s_line[i * 64 + lane] = i < 4 ? a[i] : b2[i - 4];
   };
   // the bucket of a read's window k (cmd/muscato_window_reads/main.go:106-118 ==
   // cmd/muscato_screen/main.go:174-185: long enough, CountDinuc >= MinDinuc), WB_NONE when it takes no part
@@ -305,6 +300,6 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
     if (v1) atomicAdd(&counters[3], v1);
     atomicAdd(&counters[4], (unsigned long long)used);
     atomicMax(&counters[7], (unsigned long long)used);
-    if (used > region) atomicOr(&counters[3 - 8], 1ull);  // pass-level flag: descriptor space ran out
+    if (used > region) atomicOr(pass_flags, 1ull);  // pass-level flag: descriptor space ran out
   }
 }

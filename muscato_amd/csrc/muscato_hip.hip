@@ -49,6 +49,7 @@ MUSC_LANE_INSTANCES_12(extern)
 MUSC_LANE_INSTANCES_8W(extern)
 MUSC_LANE_INSTANCES_12W(extern)
 MUSC_LANE_INSTANCES_16W(extern)
+MUSC_LANE_INSTANCES_SPEC(extern)
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -151,10 +152,54 @@ struct TmpBufs {
 
 }  // namespace
 
+// The MUSC_* environment knobs (tests, A/B runs, experiments), read ONCE per context at musc_init -- a pass
+// never calls getenv -- and again only on musc_reload_env (tests that flip a knob on a live context).
+struct EnvKnobs {
+  enum { IDX_AUTO = 0, IDX_CLASSIC, IDX_LINES, IDX_CLASSIC64 };
+  int index = IDX_AUTO;       // MUSC_INDEX = classic | lines | classic64: the two-kernel path (on that bucket layout)
+  bool match_quad = false;    // MUSC_MATCH = quad: k_match instead of k_match_t
+  bool match_lane = false;    // MUSC_MATCH = lane: k_match_t where the LDS-DMA kernel would run
+  bool screen_wg = false;     // MUSC_SCREEN = wg: k_screen on line buckets instead of k_screen_t
+  int context = 0;            // MUSC_CONTEXT = narrow (1) | wide (2)
+  bool no_x_context = false;  // MUSC_NO_X_CONTEXT
+  bool force_wide = false;    // MUSC_DEBUG_FORCE_WIDE
+  int index_bits = 0;         // MUSC_DEBUG_INDEX_BITS (0: not set)
+  int debug_grid = 0;         // MUSC_DEBUG_GRID (0: not set)
+  bool debug_sync = false;    // MUSC_DEBUG_SYNC
+  int graph = -1;             // MUSC_GRAPH: -1 not set, else its value
+  bool no_fused_compact = false;  // MUSC_NO_FUSED_COMPACT
+  bool pipeline = false;      // MUSC_PIPELINE > 0
+  bool no_spec = false;       // MUSC_NO_SPEC: never pick a geometry-specialised kernel instance
+  long batch_reads = 0;       // MUSC_BATCH_READS (0: not set)
+  void read() {
+    *this = EnvKnobs();
+    auto is = [](const char* v, const char* w) { return v && !strcmp(v, w); };
+    const char* e = getenv("MUSC_INDEX");
+    index = is(e, "classic") ? IDX_CLASSIC : is(e, "lines") ? IDX_LINES : is(e, "classic64") ? IDX_CLASSIC64 : IDX_AUTO;
+    e = getenv("MUSC_MATCH");
+    match_quad = is(e, "quad");
+    match_lane = is(e, "lane");
+    screen_wg = is(getenv("MUSC_SCREEN"), "wg");
+    e = getenv("MUSC_CONTEXT");
+    context = is(e, "narrow") ? 1 : is(e, "wide") ? 2 : 0;
+    no_x_context = getenv("MUSC_NO_X_CONTEXT") != nullptr;
+    force_wide = getenv("MUSC_DEBUG_FORCE_WIDE") != nullptr;
+    if ((e = getenv("MUSC_DEBUG_INDEX_BITS"))) index_bits = atoi(e);
+    if ((e = getenv("MUSC_DEBUG_GRID"))) debug_grid = atoi(e);
+    debug_sync = getenv("MUSC_DEBUG_SYNC") != nullptr;
+    if ((e = getenv("MUSC_GRAPH"))) graph = atoi(e);
+    no_fused_compact = getenv("MUSC_NO_FUSED_COMPACT") != nullptr;
+    if ((e = getenv("MUSC_PIPELINE"))) pipeline = atoi(e) > 0;
+    no_spec = getenv("MUSC_NO_SPEC") != nullptr;
+    if ((e = getenv("MUSC_BATCH_READS"))) batch_reads = atol(e);
+  }
+};
+
 struct musc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  EnvKnobs env;
 
   // database
   uint32_t* db2 = nullptr;
@@ -207,6 +252,7 @@ struct musc_ctx {
   MatchParams* d_mp = nullptr;  // k_match's parameter block
   MatchParams h_mp;             // what d_mp holds
   bool h_mp_valid = false;
+  int spec_geom = 0;            // the geometry-specialised k_match_t instance this pass launches (SpecGeom<n>), 0 = the general one
   DevBuf<uint4> spill;          // k_match: reported candidates beyond a tile's LDS list
 
   // reads
@@ -489,8 +535,7 @@ int check_params(musc_ctx* c, const musc_params* P) {
 // line buckets without X anywhere, record strides k_screen_t is built for: the wave-autonomous screen
 // (kernels_screen_lane.hpp); MUSC_SCREEN=wg keeps k_screen (A/B runs)
 bool screen_lane(const musc_ctx* c, bool mask) {
-  const char* se = getenv("MUSC_SCREEN");
-  return c->idx_lines && !mask && !c->rdm && (c->rw == 4 || c->rw == 8 || c->rw == 12 || c->rw == 16) && !(se && !strcmp(se, "wg"));
+  return c->idx_lines && !mask && !c->rdm && (c->rw == 4 || c->rw == 8 || c->rw == 12 || c->rw == 16) && !c->env.screen_wg;
 }
 
 // workgroups of the screen stage: the descriptor buffer is cut into that many regions.  k_screen_t's
@@ -524,7 +569,7 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
         hipLaunchKernelGGL((k_screen_t<RW>), sgrid, dim3(64), 0, c->stream, c->rd, r0, n, c->d_pp, c->nmiss_tab.p,
                            reinterpret_cast<const LineBucket*>(c->idx_T), c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,
                            c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p,
-                           c->counters + 8);
+                           c->counters + 8, c->counters + 3);
         return;
       }
     }
@@ -534,7 +579,7 @@ void launch_path(musc_ctx* c, int stage, bool mask, uint64_t r0, uint32_t n, con
     hipLaunchKernelGGL((k_screen<RW, M, O, LN>), sgrid, block, 0, c->stream, c->rd, c->rdm, r0, n, c->rw, c->d_pp, \
                        c->nmiss_tab.p, c->idx_T, c->idx_E, c->bs[c->cur].cdesc.p, c->bs[c->cur].cdesc.cap,        \
                        c->bs[c->cur].rvalid.p, c->bs[c->cur].wb.p, c->bs[c->cur].tbase.p, c->bs[c->cur].tcount.p, \
-                       c->counters + 8)
+                       c->counters + 8, c->counters + 3)
     const bool one = pp.W <= 2;
     if (c->rdm) { if (one) MUSC_LAUNCH_SCREEN(true, true); else MUSC_LAUNCH_SCREEN(true, false); }
     else { if (one) MUSC_LAUNCH_SCREEN(false, true); else MUSC_LAUNCH_SCREEN(false, false); }
@@ -613,11 +658,18 @@ int musc_init(int device_ordinal, musc_ctx** out) {
     musc_destroy(c);
     return 3;
   }
-  if (const char* br = getenv("MUSC_BATCH_READS")) {  // tests: many small batches
-    const long v = atol(br);
-    if (v >= 1 && v <= (16l << 20)) c->batch_reads = (uint32_t)v;
-  }
+  c->env.read();
+  if (c->env.batch_reads >= 1 && c->env.batch_reads <= (16l << 20)) c->batch_reads = (uint32_t)c->env.batch_reads;  // tests: many small batches
   *out = c;
+  return 0;
+}
+
+// Re-read the MUSC_* knobs (musc_init reads them once; MUSC_BATCH_READS stays as it was read then).  A test hook:
+// a knob that changes which index or kernel a pass takes makes the next pass size itself again.
+int musc_reload_env(musc_ctx* c) {
+  if (!c) return 1;
+  c->env.read();
+  c->sized_epoch = 0;
   return 0;
 }
 
@@ -780,10 +832,8 @@ extern "C++" {
 // four or more window starts per key on average and the table fits, 64-byte buckets otherwise.
 // MUSC_INDEX=lines / classic64 force one or the other.
 static bool want_line_buckets(musc_ctx* c, int32_t ww, int bits, int direct) {
-  if (const char* e = getenv("MUSC_INDEX")) {
-    if (!strcmp(e, "lines")) return true;
-    if (!strcmp(e, "classic64")) return false;
-  }
+  if (c->env.index == EnvKnobs::IDX_LINES) return true;
+  if (c->env.index == EnvKnobs::IDX_CLASSIC64) return false;
   if (!direct) return false;
   (void)ww;
   const uint64_t nb = 1ull << bits;
@@ -871,7 +921,7 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
   if (!c->db2) return fail(c, 4, "no database loaded");
   if (ww < 1 || ww > 4096) return fail(c, 2, "bad window width %d", ww);
   HIPCHK(c, hipSetDevice(c->device));
-  c->wide = c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE") != nullptr;
+  c->wide = c->nbases >= 0xFFFFFFF0ull || c->env.force_wide;
   if (c->wide && c->nseq >= (1u << 24))
     return fail(c, 5, "a database of 2^32 bases or more may hold at most 2^24 targets (has %u)", c->nseq);
   // Direct addressing (bucket = the 2*ww-bit key itself: exact, and bytewise-sorted reads walk
@@ -887,12 +937,15 @@ int musc_db_build_index(musc_ctx* c, int32_t ww) {
     bits = 10;
     while (bits < 31 && (1ull << bits) < c->nbases) bits++;
   }
-  if (const char* ov = getenv("MUSC_DEBUG_INDEX_BITS")) {  // experiments only: force a hashed table size
-    const int v = atoi(ov);
-    if (v >= 8 && v <= 31) { bits = v; direct = 0; }
-  }
+  if (c->env.index_bits >= 8 && c->env.index_bits <= 31) { bits = c->env.index_bits; direct = 0; }  // experiments only: force a hashed table size
+  // A resident window-start index for this width keeps its layout: the automatic choice looks at the free memory
+  // of the moment (want_line_buckets), which moves as the pass buffers grow, and a flip would mean dropping the
+  // sized state and rebuilding tens of gigabytes in the middle of a run.  Only an explicit MUSC_INDEX = lines |
+  // classic64 that contradicts the resident layout rebuilds.
+  if (c->idx_ww == ww && c->idx_kind == 0 && c->idx_T && c->idx_bits == bits && c->idx_direct == direct &&
+      !(c->env.index == EnvKnobs::IDX_LINES && !c->idx_lines) && !(c->env.index == EnvKnobs::IDX_CLASSIC64 && c->idx_lines))
+    return 0;
   const bool lines = want_line_buckets(c, ww, bits, direct) && bits <= 30;
-  if (c->idx_ww == ww && c->idx_kind == 0 && c->idx_T && c->idx_lines == lines) return 0;
   free_index(c);
   drop_ctx_index(c);  // one index kind is resident at a time
   c->idx_kind = 0;
@@ -926,10 +979,7 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
     bits = 10;
     while (bits < 30 && (1ull << bits) < c->nbases) bits++;
   }
-  if (const char* ov = getenv("MUSC_DEBUG_INDEX_BITS")) {  // experiments only: force a hashed table size
-    const int v = atoi(ov);
-    if (v >= 8 && v <= 30) { bits = v; direct = 0; }
-  }
+  if (c->env.index_bits >= 8 && c->env.index_bits <= 30) { bits = c->env.index_bits; direct = 0; }  // experiments only: force a hashed table size
   const uint64_t nb = 1ull << bits;
   // memory: the table, 8 B + 4 B per bucket of build temporaries, and the overflow entries (their
   // number is known only after the counting pass: assume a third of the windows for the estimate)
@@ -1038,10 +1088,8 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
 // first fused kernel, kept as a second implementation the tests run everything through as well.
 enum MatchKind { MK_QUAD = 0, MK_LANE = 2 };
 static int match_kind(const musc_ctx* c, int W) {
-  (void)c;
   (void)W;
-  const char* e = getenv("MUSC_MATCH");
-  if (e && !strcmp(e, "quad")) return MK_QUAD;
+  if (c->env.match_quad) return MK_QUAD;
   return MK_LANE;
 }
 
@@ -1067,7 +1115,7 @@ static bool reads_xpos(musc_ctx* c, int wide) {
 // per (read set, bucket width, PMatch, MaxMismatch).
 static bool reads_x_fit(musc_ctx* c, const musc_params* P, uint32_t max_len, int wide) {
   if (!c->rdm || !c->rd || !c->nreads) return false;
-  if (getenv("MUSC_NO_X_CONTEXT")) return false;
+  if (c->env.no_x_context) return false;
   if (!reads_xpos(c, wide)) return false;
   // (the budget table covers the reads in hand whatever length the caller planned the index for)
   max_len = std::max(max_len, c->max_len);
@@ -1129,15 +1177,14 @@ static bool reads_x_fit_db(musc_ctx* c, const musc_params* P, int wide) {
 // the database holds no X (the context has no mask plane; reads may hold some where
 // k_match_t runs, see reads_x_fit) and positions fit 32 bits.
 static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, int* CL, int* wide) {
-  if (const char* e = getenv("MUSC_INDEX"))
-    if (!strcmp(e, "classic") || !strcmp(e, "lines") || !strcmp(e, "classic64")) return false;  // the two-kernel path
+  if (c->env.index != EnvKnobs::IDX_AUTO) return false;  // the two-kernel path
   // (the planes themselves may exist without an X: an all-zero one is made for the side that has
   // none when the other side does, and the database's stays for the context's lifetime)
   const bool lane = match_kind(c, P->n_windows) != MK_QUAD;
   // a database with X: k_match_t only (an entry whose context holds an X is flagged in bit 31 of its
   // position, the X's place or "several: see the mask plane" in the top byte of its target number)
-  if (c->db_has_x && (!lane || c->max_tlen >= 0x80000000ull || c->nseq > (1u << 24) || getenv("MUSC_NO_X_CONTEXT"))) return false;
-  if (c->nbases >= 0xFFFFFFF0ull || getenv("MUSC_DEBUG_FORCE_WIDE")) return false;
+  if (c->db_has_x && (!lane || c->max_tlen >= 0x80000000ull || c->nseq > (1u << 24) || c->env.no_x_context)) return false;
+  if (c->nbases >= 0xFFFFFFF0ull || c->env.force_wide) return false;
   if (P->n_windows > CTX_MAX_W) return false;
   int q1min = P->windows[0], q1max = P->windows[0];
   for (int k = 1; k < P->n_windows; k++) {
@@ -1145,12 +1192,12 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
     q1max = std::max(q1max, P->windows[k]);
   }
   const int64_t span = (int64_t)q1max - q1min + (int64_t)max_len;
-  const char* wenv = getenv("MUSC_CONTEXT");  // experiments: "narrow" keeps runs beyond 120 bases on the two-kernel path, "wide" puts every run on wide buckets
+  const int wenv = c->env.context;  // experiments: "narrow" (1) keeps runs beyond 120 bases on the two-kernel path, "wide" (2) puts every run on wide buckets
   *CL = q1max;
   *wide = 0;
-  if (span > CTX_BASES || q1max > CTX_BASES || (wenv && !strcmp(wenv, "wide") && lane)) {
+  if (span > CTX_BASES || q1max > CTX_BASES || (wenv == 2 && lane)) {
     // wide buckets: k_match_t only; records of up to 16 words hold 200-base reads and their length word
-    if (!lane || (wenv && !strcmp(wenv, "narrow"))) return false;
+    if (!lane || wenv == 1) return false;
     if (span > CTXW_BASES || q1max > CTXW_BASES) return false;
     *wide = 1;
   }
@@ -1409,8 +1456,11 @@ static const void* match_fn(const musc_ctx* c, int W) {
   const int kind = match_kind(c, W);
   const bool rx = c->reads_have_x;
   if (kind == MK_LANE) {
+    if constexpr (RW == 8) {
+      if (c->spec_geom == 1) return reinterpret_cast<const void*>(&k_match_t<8, 2, 0, false, 1>);
+    }
     // (instances: 120-base buckets for records of 4, 8, 12 words; wide ones for 4 to 16)
-#define MUSC_LANE_FN2(WN, WD) (c->db_has_x ? reinterpret_cast<const void*>(&k_match_t<RW, WN, 2, WD>) : rx ? reinterpret_cast<const void*>(&k_match_t<RW, WN, 1, WD>) : reinterpret_cast<const void*>(&k_match_t<RW, WN, 0, WD>))
+#define MUSC_LANE_FN2(WN, WD) (c->db_has_x ? reinterpret_cast<const void*>(&k_match_t<RW, WN, 2, WD, 0>) : rx ? reinterpret_cast<const void*>(&k_match_t<RW, WN, 1, WD, 0>) : reinterpret_cast<const void*>(&k_match_t<RW, WN, 0, WD, 0>))
 #define MUSC_LANE_FN(WN)                                  \
   if (c->idx_wide) return MUSC_LANE_FN2(WN, true);        \
   if constexpr (RW <= 12) return MUSC_LANE_FN2(WN, false); \
@@ -1453,10 +1503,7 @@ static unsigned match_resident(musc_ctx* c, int W, int block_mode) {
   }
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
   unsigned resident = (unsigned)per_cu * (unsigned)ncu;
-  if (const char* g = getenv("MUSC_DEBUG_GRID")) {  // tests: a small grid makes every wave walk many wave-tiles of a small input
-    const int v = atoi(g);
-    if (v >= 1 && (unsigned)v < resident) resident = (unsigned)v;
-  }
+  if (c->env.debug_grid >= 1 && (unsigned)c->env.debug_grid < resident) resident = (unsigned)c->env.debug_grid;  // tests: a small grid makes every wave walk many wave-tiles of a small input
   return resident;
 }
 
@@ -1481,10 +1528,16 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
     uint4* const hp = reinterpret_cast<uint4*>(c->hits.p);
     const uint32_t* const rdx = c->reads_have_x ? (const uint32_t*)c->rdx.p : (const uint32_t*)nullptr;
     if (kind == MK_LANE) {
+      if constexpr (RW == 8) {
+        if (c->spec_geom == 1) {  // (chosen by spec_geom_matches: every specialised quantity equals the run's)
+          MUSC_LAUNCH_MATCH((k_match_t<8, 2, 0, false, 1>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx);
+          return;
+        }
+      }
 #define MUSC_LAUNCH_LANE2(WN, WD)                                                                                 \
-      if (c->db_has_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 2, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
-      else if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 1, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
-      else MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 0, WD>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
+      if (c->db_has_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 2, WD, 0>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
+      else if (c->reads_have_x) MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 1, WD, 0>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx); \
+      else MUSC_LAUNCH_MATCH((k_match_t<RW, WN, 0, WD, 0>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx)
 #define MUSC_LAUNCH_LANE(WN)                                      \
       do {                                                        \
         if (c->idx_wide) { MUSC_LAUNCH_LANE2(WN, true); }         \
@@ -1508,6 +1561,29 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
 }
 }  // extern "C++"
 
+// The geometry-specialised instance a pass may launch: SpecGeom<g> is taken only when EVERY quantity it turns into
+// a constant equals the run's -- window width, window starts, context offset, MinDinuc, the first-window sets, and
+// the TABLE: a direct table of 2 * ww bits (cfg2's 10^8-base database gets a hashed 2^27-bucket table for the same
+// ww: the general instance) -- and the instance exists for this record stride / bucket width / X mode.  Reads of
+// other lengths than the geometry's are fine: the instance falls back to per-lane length masks for such a tile.
+// MUSC_NO_SPEC=1 keeps every pass on the general instances (A/B runs, tests).
+extern "C++" {
+template <int SG>
+static bool spec_geom_equals(const MatchParams& mp) {
+  typedef SpecGeom<SG> G;
+  if (mp.W != G::nwin || mp.ww != G::ww || mp.CL != G::CL || mp.min_dinuc != G::min_dinuc || mp.direct != 1 || mp.bits != 2 * G::ww) return false;
+  for (int k = 0; k < G::nwin; k++)
+    if (mp.win[k] != G::win[k] || mp.need[k] != (1u << k) - 1u) return false;
+  return true;
+}
+}  // extern "C++"
+static int spec_geom_matches(const musc_ctx* c, const MatchParams& mp) {
+  if (c->env.no_spec || c->env.match_quad) return 0;
+  if (c->rw != 8 || c->idx_wide || c->db_has_x || c->reads_have_x) return 0;  // the instances that exist: <8, 2, 0, false, g>
+  if (spec_geom_equals<1>(mp)) return 1;
+  return 0;
+}
+
 static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& pp, int block_mode, uint32_t block_thr_unused,
                           uint64_t max_matches, uint64_t planned_batches, uint64_t* nhits) {
   int rc = 0;
@@ -1515,6 +1591,26 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     return fail(c, 12, "internal: record stride %d on the context path", c->rw);
   if (c->idx_wide && match_kind(c, pp.W) == MK_QUAD) return fail(c, 12, "internal: wide context buckets need k_match_t");
   (void)block_thr_unused;
+  // the run's parameter block (and with it the kernel instance: match_fn looks at c->spec_geom)
+  {
+    static thread_local MatchParams mp;  // 16 KB with its mask tables: not on the stack
+    memset(&mp, 0, sizeof mp);
+    mp.W = pp.W; mp.ww = pp.ww; mp.min_dinuc = pp.min_dinuc; mp.bits = pp.bits; mp.direct = pp.direct;
+    mp.mmtol = pp.mmtol; mp.apply_mmtol = pp.apply_mmtol; mp.max_len = pp.max_len; mp.CL = c->idx_CL;
+    mp.q1zero_mask = pp.q1zero_mask;
+    mp.seq_off = c->db_has_x ? c->seq_off : nullptr;
+    mp.dbm2 = c->db_has_x ? c->dbm2 : nullptr;
+    for (int k = 0; k < pp.W && k < CTX_MAX_W; k++) mp.win[k] = pp.win[k];
+    match_tables(mp);
+    c->spec_geom = spec_geom_matches(c, mp);
+    c->stats.match_variant = match_kind(c, pp.W) == MK_QUAD ? 1u : c->spec_geom ? 3u : 2u;
+    if (!c->h_mp_valid || memcmp(&mp, &c->h_mp, sizeof mp) != 0) {
+      c->h_mp = mp;
+      HIPCHK(c, hipMemcpyAsync(c->d_mp, &c->h_mp, sizeof mp, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->h_mp_valid = true;
+    }
+  }
   // the persistent grid = the workgroups that are resident at once (every wave then sees many
   // wave-tiles and the end-of-kernel atomics stay few); the MaxMatches screening threshold is per
   // workgroup-launch, so it follows the grid
@@ -1527,40 +1623,21 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
   if (block_mode == 2 && !c->block_table.p) {
     if ((rc = ensure(c, c->block_table, 1ull << BLOCK_TABLE_BITS))) return rc;
   }
-  {
-    static thread_local MatchParams mp;  // 16 KB with its mask tables: not on the stack
-    memset(&mp, 0, sizeof mp);
-    mp.W = pp.W; mp.ww = pp.ww; mp.min_dinuc = pp.min_dinuc; mp.bits = pp.bits; mp.direct = pp.direct;
-    mp.mmtol = pp.mmtol; mp.apply_mmtol = pp.apply_mmtol; mp.max_len = pp.max_len; mp.CL = c->idx_CL;
-    mp.q1zero_mask = pp.q1zero_mask;
-    mp.seq_off = c->db_has_x ? c->seq_off : nullptr;
-    mp.dbm2 = c->db_has_x ? c->dbm2 : nullptr;
-    if (const char* dv = getenv("MUSC_DEBUG_MATCH")) mp.dbg = atoi(dv);
-    for (int k = 0; k < pp.W && k < CTX_MAX_W; k++) mp.win[k] = pp.win[k];
-    match_tables(mp);
-    if (!c->h_mp_valid || memcmp(&mp, &c->h_mp, sizeof mp) != 0) {
-      c->h_mp = mp;
-      HIPCHK(c, hipMemcpyAsync(c->d_mp, &c->h_mp, sizeof mp, hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      c->h_mp_valid = true;
-    }
-  }
   const bool check_blocks = block_mode != 0;
   const bool sized = c->sized_epoch == c->data_epoch && c->sized_exact_blocks == (block_mode == 2) &&
-                     memcmp(&c->sized_params, P, sizeof *P) == 0 && !getenv("MUSC_DEBUG_SYNC");
+                     memcmp(&c->sized_params, P, sizeof *P) == 0 && !c->env.debug_sync;
   uint32_t bsz = sized ? c->sized_bsz : c->batch_reads;
   const uint64_t L = c->max_len;
   // A sized pass can be replayed as a hipGraph (MUSC_GRAPH=1): its launches, the counter memsets
   // and the final readback are captured once per (reads, database, parameters) and then cost one
   // launch per pass.  Every buffer of a sized pass is fixed, so the captured arguments stay valid;
   // any pass that sizes drops the graph.
-  const char* genv = getenv("MUSC_GRAPH");
-  const bool use_graph = sized && genv && atoi(genv) > 0 && !c->graph_failed;
+  const bool use_graph = sized && c->env.graph > 0 && !c->graph_failed;
   if (!sized && c->graph_exec) {
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
   }
-  const bool fuse_ok = match_kind(c, pp.W) != MK_QUAD && !getenv("MUSC_NO_FUSED_COMPACT");
+  const bool fuse_ok = match_kind(c, pp.W) != MK_QUAD && !c->env.no_fused_compact;
   if (sized && fuse_ok && c->nreads > bsz) {  // the second staging set (allocated outside any capture)
     if ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
         (rc = ensure(c, c->tpre_b, c->tpre.cap)))
@@ -1656,6 +1733,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
           again = true;
           break;
         }
+        if (c->h_pinned[3] & 8ull)
+          return fail(c, 12, "internal: the kernel instance specialised for geometry %d refused this run's parameters", c->spec_geom);
         if (c->h_pinned[3] || need_stage > c->stage.cap || need_spill > c->spill.cap) {
           // room for every workgroup's tuples / spilled candidates, then the pass starts over
           // (k_match has already added this batch to the pass-level counters)
@@ -1727,6 +1806,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       HIPCHK(c, hipEventRecord(ev1, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_pinned[3] & 8ull)
+      return fail(c, 12, "internal: the kernel instance specialised for geometry %d refused this run's parameters", c->spec_geom);
     if (c->h_pinned[3]) {
       if (!sized) return fail(c, 12, "internal: a capacity guard fired although every batch was sized (flags %llu)",
                               (unsigned long long)c->h_pinned[3]);
@@ -1799,7 +1880,6 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   pp.apply_mmtol = P->apply_mmtol;
   pp.wide = c->wide;
   pp.max_len = (int32_t)c->max_len;
-  if (const char* dv = getenv("MUSC_DEBUG_SCREEN")) pp.dbg = atoi(dv);
   for (int k = 0; k < pp.W; k++) {
     pp.win[k] = P->windows[k];
     if (P->windows[k] == 0) pp.q1zero_mask |= 1u << k;
@@ -1848,6 +1928,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     c->h_pp_valid = true;
   }
   c->stats.index_kind = c->idx_kind == 1 ? (c->idx_wide ? 2u : 1u) : (c->idx_lines ? 3u : 0u);
+  c->stats.match_variant = 0;  // (match_ctx_pass says which fused kernel it launches)
   c->stats.index_bytes = c->idx_kind == 1
                              ? ((1ull << c->idx_bits) + 1) * sizeof(CtxBucket) + ctx_entries_bytes(c->idx_novf + 16, c->idx_wide)
                              : ((1ull << c->idx_bits) + 1) * (c->idx_lines ? sizeof(LineBucket) : sizeof(Bucket)) + (c->idx_novf + 16) * sizeof(uint4);
@@ -1879,7 +1960,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   // completed one ("sized") is known to fit and runs without any host round trip; every kernel
   // still guards its writes, and the flags are checked once at the end.
   const bool sized = c->sized_epoch == c->data_epoch && c->sized_exact_blocks == (block_mode == 2) &&
-                     memcmp(&c->sized_params, P, sizeof *P) == 0 && !getenv("MUSC_DEBUG_SYNC");
+                     memcmp(&c->sized_params, P, sizeof *P) == 0 && !c->env.debug_sync;
   uint64_t n_cand = 0, n_pairs = 0, n_windows = 0, n_two = 0;
   const uint64_t PAIR_CAP = 1ull << 31;  // u32 descriptor offsets
   uint64_t r0 = 0;
@@ -1890,8 +1971,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   // Off by default: measured on cfg3 / cfg4 / cfg5 shards the pass moves ~5.6 TB/s of cache lines
   // through HBM either way (both kernels are bound by the lines they fetch), so overlapping them
   // gains nothing (5.66 vs 5.44 ms on cfg3) and the second set costs memory.
-  const char* pipe_env = getenv("MUSC_PIPELINE");
-  const bool want_pipe = pipe_env && atoi(pipe_env) > 0;
+  const bool want_pipe = c->env.pipeline;
   const bool piped = sized && want_pipe && c->nreads > bsz && c->bs[1].cdesc.cap >= c->bs[0].cdesc.cap;
   hipStream_t sA = c->stream, sB = piped ? c->stream2 : c->stream;
   c->s_confirm = sB;
@@ -2045,7 +2125,6 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   }
   c->stats.ms_screen = tm.total(0);
   c->stats.ms_scan = tm.total(1);
-  c->stats.ms_unused0 = tm.total(2);
   c->stats.ms_confirm = tm.total(3);
   c->stats.ms_select = tm.total(4);
   (void)hipEventElapsedTime(&c->stats.ms_total, ev0, ev1);

@@ -17,7 +17,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.musc_abi_version() == 2
+    assert lib.musc_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

@@ -268,6 +268,7 @@ def test_cfg3_with_x_in_the_database_at_full_size(monkeypatch):
         for path in ("context", "two-kernel"):
             if path == "two-kernel":
                 monkeypatch.setenv("MUSC_NO_X_CONTEXT", "1")
+                eng.reload_env()  # (the library reads its MUSC_* knobs once per context)
             n_all = eng.match_device(cfg, apply_mmtol=False)
             st = eng.stats()
             _log("cfg3 + X in the database, %s path (index kind %d): %d reads -> %d accepted tuples, device %.2f ms"

@@ -648,6 +648,7 @@ def test_index_selection(monkeypatch):
         assert eng.stats()["index_kind"] == 1
         assert_same(got, as_arr(orc.match_direct(reads, xt, ocfg)))
         monkeypatch.setenv("MUSC_NO_X_CONTEXT", "1")
+        eng.reload_env()  # (the library reads its MUSC_* knobs once per context)
         got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
         assert eng.stats()["index_kind"] == 0
         assert_same(got, as_arr(orc.match_direct(reads, xt, ocfg)))
@@ -655,6 +656,7 @@ def test_index_selection(monkeypatch):
         eng.load_targets(targets)
         # forced
         monkeypatch.setenv("MUSC_INDEX", "classic")
+        eng.reload_env()
         reads = reads_of(100)
         ocfg = orc.Config(Windows=[0, 20], WindowWidth=12, PMatch=0.9, MinDinuc=2, MaxReadLength=100, MaxMatches=100000)
         eng.load_reads(reads)
@@ -663,6 +665,7 @@ def test_index_selection(monkeypatch):
         assert_same(got, as_arr(orc.match_direct(reads, targets, ocfg)))
         # musc_db_build_index_for builds what the match then uses (no rebuild: the timing stays)
         monkeypatch.delenv("MUSC_INDEX", raising=False)
+        eng.reload_env()
         eng.build_index_for(to_cfg(ocfg), 100)
         ms = eng.stats()["ms_index_build"]
         got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
@@ -776,11 +779,13 @@ def test_graph_replay_of_the_sized_pass(monkeypatch):
                 eng.load_reads(reads)
                 for mode in (True, False):
                     monkeypatch.delenv("MUSC_GRAPH", raising=False)
+                    eng.reload_env()
                     exp = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=mode))
                     st0 = eng.stats()
                     assert st0["index_kind"] == 1
                     monkeypatch.setenv("MUSC_GRAPH", "1")
-                    for rep in range(3):  # capture, replay, replay
+                    eng.reload_env()  # (the next pass sizes itself again; then capture, replay)
+                    for rep in range(4):  # sizing pass, capture, replay, replay
                         got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=mode))
                         st = eng.stats()
                         assert (got == exp).all() and all(st[k] == st0[k] for k in keys), (seed, L, mode, rep)
