@@ -656,8 +656,11 @@ def main() -> int:
             ach_s = (b_s / 1e9) / (ms_m / 1e3) if ms_m > 0 else 0.0
             nlm = max(st["match_launches"], 1)
             # which of the two kernels ran (match_kind in muscato_hip.hip): k_match_t unless MUSC_MATCH=quad
-            lane = os.environ.get("MUSC_MATCH") != "quad"
-            kname = "k_match_t" if lane else "k_match"
+            # which of the fused kernels ran (musc_stats.match_variant): 1 k_match, 2 / 3 k_match_t general / specialised
+            # for the run's geometry, 4 / 5 k_match_g (three waves per SIMD, LDS-DMA) general / specialised
+            mv = st.get("match_variant", 2)
+            lane = mv != 1
+            kname = {1: "k_match", 2: "k_match_t", 3: "k_match_t<geometry 1>", 4: "k_match_g", 5: "k_match_g<geometry 1>"}.get(mv, "k_match_t")
             fused_note = ("from the second launch of a pass on, a launch also moves the previous batch's staged tuples "
                           "into the hit list (32 B of traffic per tuple), which `achieved` does not bill"
                           if lane and st["match_launches"] > 1 else None)
@@ -665,7 +668,7 @@ def main() -> int:
                 "kernel": kname + " (screen + confirm + per-read selection, context buckets)", "bound": "hbm",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
-                "traffic": measured_traffic(tkey, kname) if not args.reads else None,
+                "traffic": measured_traffic(tkey, kname.split("<")[0]) if not args.reads else None,
                 "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc passes of this command, recorded; not measured by this run)",
                 "algorithmic_bytes": "%d B per read record + 128 B bucket line per probe + %d B per overflow entry walked + "
                                      "16 B per tuple staged" % (rec_b, 60 if kind == 2 else 40),

@@ -103,7 +103,8 @@ typedef struct {
                              *   k_confirm (index_kind 0 only) | scan+k_compact            */
   uint32_t match_variant;   /* (ABI 3; the slot was an unused float) which fused kernel ran on context buckets:
                              * 0 = none (two-kernel path), 1 = k_match (quad per probe), 2 = k_match_t, general
-                             * instance, 3 = k_match_t specialised for the run's geometry (SpecGeom<1>)        */
+                             * instance, 3 = k_match_t specialised for the run's geometry (SpecGeom<1>),
+                             * 4 = k_match_g (three waves per SIMD, LDS-DMA), general, 5 = k_match_g specialised */
   float ms_confirm;
   float ms_select;
   float ms_total;           /* first launch to last completion on the context's stream  */

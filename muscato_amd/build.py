@@ -13,10 +13,11 @@ OBJ = os.path.join(HERE, "build")
 # one translation unit for the host side and most kernels, and one per record stride for k_match_t
 # (kernels_match_lane_inst.hpp): they compile side by side
 SOURCES = [os.path.join(CSRC, f) for f in ("muscato_hip.hip", "match_lane_rw4.hip", "match_lane_rw8.hip", "match_lane_rw12.hip",
-                                           "match_lane_rw8w.hip", "match_lane_rw12w.hip", "match_lane_rw16w.hip", "match_lane_rw8s.hip")]
+                                           "match_lane_rw8w.hip", "match_lane_rw12w.hip", "match_lane_rw16w.hip", "match_lane_rw8s.hip", "match_dma_rw8.hip")]
 HEADERS = [os.path.join(os.path.dirname(HERE), "include", "muscato_hip.h")] + \
     [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
 LANE_ONLY = os.path.join(CSRC, "kernels_match_lane.hpp")  # k_match_t's definition: muscato_hip.hip sees its declaration only
+DMA_ONLY = os.path.join(CSRC, "kernels_match_dma.hpp")    # k_match_g's definition, likewise
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -61,7 +62,8 @@ def build_tools(force: bool = False, verbose: bool = False) -> None:
 
 def _compile(src: str, force: bool, verbose: bool, defines=(), tag: str = "") -> str:
     obj = os.path.join(OBJ, os.path.basename(src) + tag + ".o")
-    deps = [src] + [h for h in HEADERS if h != LANE_ONLY or "match_lane" in os.path.basename(src)]
+    base = os.path.basename(src)
+    deps = [src] + [h for h in HEADERS if (h != LANE_ONLY or "match_lane" in base or "match_dma" in base) and (h != DMA_ONLY or "match_dma" in base)]
     if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj
     cmd = [hipcc()] + FLAGS + list(defines) + ["-c", "-o", obj, src]
@@ -94,8 +96,8 @@ def variant(name: str, defines) -> str:
         # (-DMAIN... flags go to the main unit, everything else to the k_match_t units)
         main_defs = ["-D" + d[len("-DMAIN_"):] for d in defines if d.startswith("-DMAIN_")]
         lane_defs = [d for d in defines if not d.startswith("-DMAIN_")]
-        objs = list(ex.map(lambda s: _compile(s, False, False, lane_defs if "match_lane" in s else main_defs,
-                                              "." + name if ("match_lane" in s and lane_defs) or ("match_lane" not in s and main_defs) else ""), SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, False, False, lane_defs if ("match_lane" in s or "match_dma" in s) else main_defs,
+                                              "." + name if (("match_lane" in s or "match_dma" in s) and lane_defs) or ("match_lane" not in s and "match_dma" not in s and main_defs) else ""), SOURCES))
     out = os.path.join(out_dir, name + ".so")
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     return out

@@ -43,6 +43,31 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
                                                                 const uint32_t* __restrict__ ptpre, uint32_t pnwt,
                                                                 uint4* __restrict__ hits, uint64_t hits_cap,
                                                                 const uint32_t* __restrict__ rdx);
+// k_match_g (kernels_match_dma.hpp): the same kernel at three waves per SIMD -- lines, overflow entries and records by
+// LDS-DMA -- for two windows on 120-base buckets without X (BASELINE configs 2-4); general (SG = 0) and specialised
+#ifndef MATCHG_WAVES
+#define MATCHG_WAVES 3
+#endif
+#ifndef MATCHG_WLIST
+#define MATCHG_WLIST 64  // reported candidates of a wave-tile kept in LDS (cfg3: ~53); more spill to HBM
+#endif
+template <int RW, int SG>
+__global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
+                                                                const MatchParams* __restrict__ mp,
+                                                                const uint16_t* __restrict__ nmiss_tab,
+                                                                const CtxBucket* __restrict__ T, const CtxEntry* __restrict__ E,
+                                                                uint4* __restrict__ stage, uint64_t stage_cap,
+                                                                uint4* __restrict__ spill, uint64_t spill_cap,
+                                                                uint32_t* __restrict__ tbase, uint32_t* __restrict__ tcount2,
+                                                                int block_mode, uint32_t block_thr,
+                                                                uint32_t* __restrict__ block_table,
+                                                                unsigned long long* __restrict__ counters);
+#define MUSC_DMA_ARGS                                                                                                  \
+  (const uint32_t*, uint64_t, uint32_t, const MatchParams*, const uint16_t*, const CtxBucket*, const CtxEntry*, uint4*, \
+   uint64_t, uint4*, uint64_t, uint32_t*, uint32_t*, int, uint32_t, uint32_t*, unsigned long long*)
+#define MUSC_DMA_INSTANCES(X)                            \
+  X template __global__ void k_match_g<8, 0> MUSC_DMA_ARGS; \
+  X template __global__ void k_match_g<8, 1> MUSC_DMA_ARGS;
 #define MUSC_LANE_ARGS                                                                                              \
   (const uint32_t*, uint64_t, uint32_t, const MatchParams*, const uint16_t*, const CtxBucket*, const CtxEntry*, uint4*, \
    uint64_t, uint4*, uint64_t, uint32_t*, uint32_t*, int, uint32_t, uint32_t*, unsigned long long*, const uint4*,   \

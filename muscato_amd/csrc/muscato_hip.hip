@@ -50,6 +50,7 @@ MUSC_LANE_INSTANCES_8W(extern)
 MUSC_LANE_INSTANCES_12W(extern)
 MUSC_LANE_INSTANCES_16W(extern)
 MUSC_LANE_INSTANCES_SPEC(extern)
+MUSC_DMA_INSTANCES(extern)
 
 // ------------------------------------------------------------------------------------
 // host side
@@ -1086,10 +1087,13 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
 // Which of the kernels on context buckets runs: k_match_t (comparisons in the lane that owns the read,
 // kernels_match_lane.hpp); MUSC_MATCH=quad selects k_match (comparison where the line arrives), the
 // first fused kernel, kept as a second implementation the tests run everything through as well.
-enum MatchKind { MK_QUAD = 0, MK_LANE = 2 };
+enum MatchKind { MK_QUAD = 0, MK_LANE = 2, MK_DMA = 3 };
+// MK_DMA = k_match_g (kernels_match_dma.hpp): k_match_t's comparisons at three waves per SIMD, everything from memory by
+// LDS-DMA -- built for two windows on 120-base buckets, records of 8 words, no X on either side (BASELINE configs
+// 2-4); MUSC_MATCH=lane keeps such runs on k_match_t (A/B runs, and the parity tests run both)
 static int match_kind(const musc_ctx* c, int W) {
-  (void)W;
   if (c->env.match_quad) return MK_QUAD;
+  if (!c->env.match_lane && W == 2 && c->rw == 8 && c->idx_kind == 1 && !c->idx_wide && !c->db_has_x && !c->reads_have_x) return MK_DMA;
   return MK_LANE;
 }
 
@@ -1446,6 +1450,7 @@ int musc_reads_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t*
 extern "C++" {
 static size_t match_dyn_lds(int kind, int W, int block_mode) {
   // per-(window, read) counters of the wave-tile in hand (k_match_t: of two wave-tiles), then (mode 1) the sketch
+  if (kind == MK_DMA) return block_mode == 1 ? (size_t)(4u << MATCH_SKETCH_BITS) : 0u;  // (its per-(window, read) counters are registers)
   const size_t wcnt = (size_t)TILE * W * 4 * (kind == MK_LANE ? 2 : 1);  // TILE = 4 waves x 64
   return block_mode ? wcnt + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;
 }
@@ -1455,6 +1460,10 @@ template <int RW>
 static const void* match_fn(const musc_ctx* c, int W) {
   const int kind = match_kind(c, W);
   const bool rx = c->reads_have_x;
+  if (kind == MK_DMA) {
+    if constexpr (RW == 8) return c->spec_geom == 1 ? reinterpret_cast<const void*>(&k_match_g<8, 1>) : reinterpret_cast<const void*>(&k_match_g<8, 0>);
+    else return nullptr;
+  }
   if (kind == MK_LANE) {
     if constexpr (RW == 8) {
       if (c->spec_geom == 1) return reinterpret_cast<const void*>(&k_match_t<8, 2, 0, false, 1>);
@@ -1521,6 +1530,13 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
   hipLaunchKernelGGL(K, grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,                       \
                      c->ctx_T, c->ctx_E, st.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,          \
                      tc.p, block_mode, block_thr, c->block_table.p, c->counters, ##__VA_ARGS__)
+  if (kind == MK_DMA) {
+    if constexpr (RW == 8) {
+      if (c->spec_geom == 1) MUSC_LAUNCH_MATCH((k_match_g<8, 1>));
+      else MUSC_LAUNCH_MATCH((k_match_g<8, 0>));
+    }
+    return;
+  }
   if (kind != MK_QUAD) {
     const uint4* pst = prev_tiles ? (set ? c->stage.p : c->stage_b.p) : nullptr;
     const uint32_t* ptc = set ? c->tcount2.p : c->tcount2_b.p;
@@ -1603,7 +1619,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     for (int k = 0; k < pp.W && k < CTX_MAX_W; k++) mp.win[k] = pp.win[k];
     match_tables(mp);
     c->spec_geom = spec_geom_matches(c, mp);
-    c->stats.match_variant = match_kind(c, pp.W) == MK_QUAD ? 1u : c->spec_geom ? 3u : 2u;
+    c->stats.match_variant = match_kind(c, pp.W) == MK_QUAD ? 1u : (match_kind(c, pp.W) == MK_DMA ? 4u : 2u) + (c->spec_geom ? 1u : 0u);
     if (!c->h_mp_valid || memcmp(&mp, &c->h_mp, sizeof mp) != 0) {
       c->h_mp = mp;
       HIPCHK(c, hipMemcpyAsync(c->d_mp, &c->h_mp, sizeof mp, hipMemcpyHostToDevice, c->stream));
@@ -1637,7 +1653,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
   }
-  const bool fuse_ok = match_kind(c, pp.W) != MK_QUAD && !c->env.no_fused_compact;
+  const bool fuse_ok = match_kind(c, pp.W) == MK_LANE && !c->env.no_fused_compact;  // (k_match_t moves the previous batch's tuples from inside its launch)
   if (sized && fuse_ok && c->nreads > bsz) {  // the second staging set (allocated outside any capture)
     if ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
         (rc = ensure(c, c->tpre_b, c->tpre.cap)))
