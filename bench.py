@@ -655,12 +655,11 @@ def main() -> int:
             ach = (b_m / 1e9) / (ms_m / 1e3) if ms_m > 0 else 0.0
             ach_s = (b_s / 1e9) / (ms_m / 1e3) if ms_m > 0 else 0.0
             nlm = max(st["match_launches"], 1)
-            # which of the two kernels ran (match_kind in muscato_hip.hip): k_match_t unless MUSC_MATCH=quad
-            # which of the fused kernels ran (musc_stats.match_variant): 1 k_match, 2 / 3 k_match_t general / specialised
+            # which of the fused kernels ran (musc_stats.match_variant): 2 / 3 k_match_t general / specialised
             # for the run's geometry, 4 / 5 k_match_g (three waves per SIMD, LDS-DMA) general / specialised
             mv = st.get("match_variant", 2)
-            lane = mv != 1
-            kname = {1: "k_match", 2: "k_match_t", 3: "k_match_t<geometry 1>", 4: "k_match_g", 5: "k_match_g<geometry 1>"}.get(mv, "k_match_t")
+            lane = True
+            kname = {2: "k_match_t", 3: "k_match_t<geometry 1>", 4: "k_match_g", 5: "k_match_g<geometry 1>"}.get(mv, "k_match_t")
             fused_note = ("from the second launch of a pass on, a launch also moves the previous batch's staged tuples "
                           "into the hit list (32 B of traffic per tuple), which `achieved` does not bill"
                           if lane and st["match_launches"] > 1 else None)

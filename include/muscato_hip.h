@@ -102,7 +102,7 @@ typedef struct {
   float ms_scan;            /*   k_screen (index_kind 0) or k_match (1) | scan | (see match_variant) |
                              *   k_confirm (index_kind 0 only) | scan+k_compact            */
   uint32_t match_variant;   /* (ABI 3; the slot was an unused float) which fused kernel ran on context buckets:
-                             * 0 = none (two-kernel path), 1 = k_match (quad per probe), 2 = k_match_t, general
+                             * 0 = none (two-kernel path), 2 = k_match_t, general
                              * instance, 3 = k_match_t specialised for the run's geometry (SpecGeom<1>),
                              * 4 = k_match_g (three waves per SIMD, LDS-DMA), general, 5 = k_match_g specialised */
   float ms_confirm;

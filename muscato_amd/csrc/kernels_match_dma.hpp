@@ -1,48 +1,41 @@
-// k_match_g -- the fused screen + confirm + select kernel at THREE waves per SIMD (round 4; device code, compiled in
-// match_dma_rw8.hip, declared in kernels_match_lane_inst.hpp; bucket layout, parameter block and fit rules of
+// k_match_g -- the fused screen + confirm + select kernel at THREE TO FOUR waves per SIMD (round 4; device code, compiled
+// in match_dma_rw8.hip, declared in kernels_match_lane_inst.hpp; bucket layout, parameter block and fit rules of
 // kernels_match.hpp; the comparison itself is k_match_t's: in the lane that owns the read).
 //
 // k_match_t (kernels_match_lane.hpp) lands a window's 64 bucket lines in 32 registers, writes them to a line buffer,
 // keeps two generations of records, candidate lists and per-read tables in LDS and carries a wave-tile's overflow
 // entries in registers across the tile boundary: 211-225 VGPRs and 16 KB of LDS per wave = two waves per SIMD, and
 // r03's counters said what that costs: 43 % of a wave's cycles execute, 39 % wait, with ONE other wave to cover them.
-// Here everything that comes from memory travels by LDS-DMA (global_load_lds_dwordx4: the data goes from the L2 to
-// LDS, no destination register, no ds_write pass):
+// Here a wave owns ONE 8 KB buffer and everything that comes from memory lands in it by LDS-DMA
+// (global_load_lds_dwordx4: L2 -> LDS, no destination register, no ds_write pass):
 //   * the 64 lines of a window: eight instructions of EIGHT WHOLE LINES each (eight lanes per line, 16 contiguous
 //     bytes per lane; the per-lane SOURCE address picks the chunk that belongs at the lane's place in the swizzled
-//     line buffer -- chunk c of line p at slot c ^ ((p >> 1) & 7) ^ (p & 1) -- so lane p reads line p without bank
+//     buffer -- chunk c of line p at slot c ^ ((p >> 1) & 7) ^ (p & 1) -- so lane p reads line p without bank
 //     conflicts, exactly as in k_match_t);
-//   * the overflow entries of the wave-tile before (beyond a bucket's third, 40 bytes each): three 16-byte pieces per
-//     entry into a landing zone Z of 48 entries (the pieces' tails belong to the entry's line: ctx_entry_word);
-//   * the NEXT wave-tile's records: 64 * RW words in a row = RW / 4 instructions of 1 KB, into the same zone.
-// ONE line buffer per wave (8 KB), ONE generation of candidate list / best / meta, no records in LDS (a lane keeps
-// its read's record in registers; an overflow entry's lane gets its read's record by ds_bpermute when it is listed):
-// 11.8 KB of LDS per wave and ~130-160 VGPRs = three workgroups of four waves per CU.
+//   * then, in the same buffer, the wave-tile's overflow entries (beyond a bucket's third, 40 bytes each: three
+//     16-byte pieces per entry -- the pieces' tails belong to the entry's line, ctx_entry_word -- 64 entries per
+//     round) next to the NEXT wave-tile's records (64 * RW words in a row = RW / 4 instructions of 1 KB);
+//   * and phase D's per-read tables (best, count, base) once the entries have been compared.
+// No state crosses a wave-tile boundary but the next tile's record, buckets and meta word: no second generation of
+// anything.  A lane keeps its read's record in registers; an overflow entry's lane gets its read's record and meta
+// word by ds_bpermute.  9 KB of LDS per wave, <= 128 VGPRs: FOUR workgroups of four waves per CU.
 //
-// The schedule of a wave-tile t (two windows; "flight" = LDS-DMA issued ... s_waitcnt):
-//   F1  issue [overflow entries of t-1 -> Z] then [lines of window 0 of t -> line buffer]
-//       s_waitcnt vmcnt(8): the entries are there, the eight line instructions still fly --
-//         compare the overflow entries of t-1 (a lane per entry), phase D of t-1 (per-read selection, tuples)
-//         the read's image for window 0 of t
-//       s_waitcnt vmcnt(0): header + the three inline entries of window 0, in the lane that owns the read
-//   F2  issue [lines of window 1 of t -> line buffer] and [records of t+1 -> Z]
-//         the read's image for window 1
-//       s_waitcnt vmcnt(0): records of t+1 -> registers, its phase A (window gates, buckets);
-//       header + inline entries of window 1; the overflow entries of t are listed (item tables -> Z)
-// A wave exposes most of two memory round trips per wave-tile -- by design: the third wave of its SIMD (and the
-// fourth ... twelfth of its CU) is what covers them, and with twelve waves per CU the memory system stays full.
-// All vector-memory traffic of the loop is LDS-DMA or a store (the compiler's waitcnt insertion cannot see an
-// LDS-DMA; every wait for one is written out here, and nothing the compiler waits for with vmcnt(0) -- it always
-// drains -- is in flight while a line flight is, except on the rare paths that say so).
+// The schedule of a wave-tile (two windows; "flight" = LDS-DMA issued ... s_waitcnt vmcnt(0)):
+//   F1  lines of window 0 -> buffer | the read's image and the mask tables for window 0 | wait | header + the three
+//       inline entries, in the lane that owns the read
+//   F2  the same for window 1; then the overflow entries of both windows are listed (a lane per entry)
+//   F3  overflow entries + the next wave-tile's records -> buffer | wait | the entries' comparison pass, phase D
+//       (per-read best + MMTol selection, tuples), the next wave-tile's phase A
+// A wave exposes its three memory round trips -- by design: fifteen other waves on its CU cover them and keep the
+// memory system full, where k_match_t had seven and hid one round trip behind its own arithmetic.  All vector-memory
+// traffic of the loop is LDS-DMA or a store (the compiler's waitcnt insertion cannot see an LDS-DMA: every wait for
+// one is written out here), except the rare paths that say so.
 //
 // Built for two windows on 120-base buckets, no X on either side (BASELINE configs 2-4); every other run keeps
-// k_match_t.  The tuples of a batch are moved into `hits` by k_compact_w (no in-launch move of the previous batch).
+// k_match_t.
 #pragma once
 #include "kernels_match_lane_inst.hpp"
 
-#ifndef MATCHG_ZITEMS
-#define MATCHG_ZITEMS 48  // overflow entries per landing round (48 bytes each)
-#endif
 
 // one LDS-DMA instruction: every active lane's 16 bytes at gsrc land at lds_dst + 16 * lane (lds_dst wave-uniform)
 DEV void glds16(const void* gsrc, uint32_t lds_dst) {
@@ -75,13 +68,12 @@ DEV void glds16x8(const void* p0, const void* p1, const void* p2, const void* p3
 #undef MUSC_GLDS_LINE
 }
 DEV void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-DEV void wait_vm8() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 // the byte address of a __shared__ object within the workgroup's LDS, wave-uniform (what M0 wants)
 template <class T>
 DEV uint32_t lds_addr(const T* p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p); }
 
 template <int RW, int SG>
-__global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
+__global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
                                                                 const CtxBucket* __restrict__ T, const CtxEntry* __restrict__ E,
@@ -90,21 +82,28 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
                                                                 uint32_t* __restrict__ tbase, uint32_t* __restrict__ tcount2,
                                                                 int block_mode, uint32_t block_thr,
                                                                 uint32_t* __restrict__ block_table,
-                                                                unsigned long long* __restrict__ counters) {
+                                                                unsigned long long* __restrict__ counters,
+                                                                const uint4* __restrict__ pstage, const uint32_t* __restrict__ ptcount2,
+                                                                const uint32_t* __restrict__ ptpre, uint32_t pnwt,
+                                                                uint4* __restrict__ hits, uint64_t hits_cap,
+                                                                const uint32_t* __restrict__ rdx) {
+  (void)rdx;  // (reads with X stay with k_match_t)
   constexpr int W = 2, NW = 8, NIN = CTX_INLINE;
   constexpr int NWAVE = TILE / 64;
-  constexpr uint32_t WLIST = (uint32_t)MATCHG_WLIST, ZI = (uint32_t)MATCHG_ZITEMS;
-  static_assert(RW % 4 == 0 && RW / 4 * 64 <= 3 * MATCHG_ZITEMS, "the next wave-tile's records land in the overflow entries' zone");
-  static_assert(MATCHG_ZITEMS % 4 == 0 && MATCHG_ZITEMS <= 64 && 3 * MATCHG_ZITEMS >= 32 + 16 + 4, "the zone (3 ZI uint4) also holds phase D's cnt / base (32 uint4) and the item tables (16 + 4)");
+  constexpr uint32_t WLIST = (uint32_t)MATCHG_WLIST;
+  static_assert(RW % 4 == 0 && RW <= 8, "the next wave-tile's records land in 2 KB of the wave's buffer");
   extern __shared__ uint32_t s_dyn[];                      // block_mode == 1: the MaxMatches sketch of the workgroup
-  __shared__ uint4 s_line[NWAVE][64 * 8];                  // the window's 64 bucket lines, swizzled
-  // the landing zone, by phase: overflow entries (three planes of ZI x 16 bytes) | the next wave-tile's records |
-  // phase D's cnt[64], base[64] | the item tables of the overflow entries just listed (s_oix at uint4 32.., s_own at 48..)
-  __shared__ uint4 s_z[NWAVE][3 * MATCHG_ZITEMS];
+  // The wave's buffer, 512 x 16 bytes, by phase:
+  //   F1 / F2  [0, 512)    the window's 64 bucket lines, swizzled
+  //   F3       [0, 192)    the overflow entries in hand: three planes of 64 x 16 bytes
+  //            [192, 256)  the first 64 tuples the PREVIOUS batch's launch staged for this wave-tile, on their way to `hits`
+  //            [256, 384)  the next wave-tile's records
+  //            [384, 400)  best[64]: smallest mismatch count the entries' pass reported per read
+  //            [400, 416)  phase D: cnt[64]      [416, 432)  base[64]
+  //            [432, 448)  item -> its entry in E (64 words)   [448, 452)  item -> window * 64 + read slot (64 bytes)
+  __shared__ uint4 s_line[NWAVE][64 * 8];
   __shared__ uint3 s_list[NWAVE][WLIST];                   // reported candidates: result word, gene, position
-  __shared__ uint32_t s_best[NWAVE][WT];                   // smallest mismatch count the overflow pass reported per read
-  __shared__ uint32_t s_meta[NWAVE][WT];                   // length | budget << 17 | valid windows << 24
-  __shared__ uint16_t s_nm[CONF_NM];
+  __shared__ uint16_t s_nm[CONF_NM / 2];                   // (reads on this path are at most 112 bases)
 
   typedef SpecGeom<SG> SGm;
   constexpr bool SPEC = SGm::on;
@@ -128,10 +127,9 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
 #pragma unroll
   for (int k = 0; k < W; k++) win[k] = SPEC ? S_WIN[k] : mp->win[k];
   uint32_t* const s_sketch = s_dyn;
-  for (uint32_t t = threadIdx.x; t < CONF_NM; t += TILE) s_nm[t] = t <= (uint32_t)mp->max_len ? nmiss_tab[t] : (uint16_t)0;
+  for (uint32_t t = threadIdx.x; t < CONF_NM / 2; t += TILE) s_nm[t] = t <= (uint32_t)mp->max_len ? nmiss_tab[t] : (uint16_t)0;
   if (block_mode == 1)
-    for (uint32_t t = threadIdx.x; t < (1u << MATCH_SKETCH_BITS); t += TILE) s_sketch[t] = 0;
-  s_best[threadIdx.x >> 6][threadIdx.x & 63] = 0xFFFFFFFFu;
+    for (uint32_t t = threadIdx.x; t < (1u << MATCHG_SKETCH_BITS); t += TILE) s_sketch[t] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) tcount2[(n + WT - 1) / WT] = 0;
   __syncthreads();
 
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
       }
     }
     nvalid += __popc(valid);
-    const uint32_t budget0 = (uint32_t)len < CONF_NM ? s_nm[len] : 0u;  // (reads on this path are at most 120 bases)
+    const uint32_t budget0 = (uint32_t)len < CONF_NM / 2 ? s_nm[len] : 0u;
     return (uint32_t)len | ((budget0 > 127u ? 127u : budget0) << 17) | (valid << 24);
   };
   // the LDS-DMA of one window's 64 lines into this wave's line buffer: bbk = this lane's read's bucket for that window;
@@ -287,29 +285,30 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
     return w;
   };
 
-  // ---- state: the wave-tile in hand ("cur": record, buckets, meta word in registers), the next one (filled by F2)
-  // and the one before ("prev": its first ZI overflow entries are listed in the zone, each with its read's record
-  // and meta word in its lane's registers; its candidates wait in s_list / s_best for its phase D in cur's F1)
+  // The tuples the PREVIOUS batch's launch staged (pstage != nullptr: same grid, same regions, the other stage buffer)
+  // move to their final place in `hits` from inside this launch (the protocol of match_ctx_pass, as in k_match_t): a
+  // wave-tile's first 64 ride in F3's flight through the buffer, the rest (rare) by plain loads behind its wait
+  bool pcopy = pstage != nullptr;
+  unsigned long long pbase = 0;
+  if (pcopy) {
+    pbase = counters[2];
+    if (pbase + ptpre[pnwt] > hits_cap) {  // cannot happen on a sized pass
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&counters[3], 2ull);
+      pcopy = false;
+    }
+  }
+  uint64_t pused = 0;  // tuples of the previous batch this wave has moved (its region is consumed in order)
+  // ---- state that crosses a wave-tile boundary: the record, buckets and meta word of the wave-tile in hand
   Rec<RW> rec_cur;
   rec_cur.zero();
   uint32_t meta_cur = 0, bb_cur[W];
 #pragma unroll
   for (int k = 0; k < W; k++) bb_cur[k] = WB_NONE;
-  uint32_t wt_prev = 0, nlist_prev = 0, best_prev = 0xFFFFFFFFu, ulen_prev = 0xFFFFFFFFu, total_prev = 0;
-  uint32_t wc_prev[W], bb_prev[W], oc_prev[W], ovf_prev[W];
-#pragma unroll
-  for (int k = 0; k < W; k++) wc_prev[k] = oc_prev[k] = ovf_prev[k] = 0, bb_prev[k] = WB_NONE;
-  uint32_t o_n = 0, o_ks = 0, o_meta = 0, o_eix = 0;  // this lane's item: window << 6 | read slot, the read's meta word, its entry in E
-  Rec<RW> o_rec;
-  o_rec.zero();
-
   if (gw < nwt) {
     const uint32_t i = gw * WT + (opaque(threadIdx.x) & 63);
-    rec_cur.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);  // (the one plain load of the kernel: nothing is in flight yet)
+    rec_cur.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);  // (the one plain load of the loop-free part: nothing is in flight yet)
     meta_cur = phase_a(gw, rec_cur, bb_cur);
   }
-  uint32_t wt = gw;
-  bool have_prev = false;
 #ifdef MUSC_LANE_PROF
   unsigned long long pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime(), pstart = pt0;
   uint32_t pf_tiles = 0;
@@ -317,72 +316,170 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
 #else
 #define PF(i)
 #endif
-  while (wt < nwt || have_prev) {
-    const bool have_cur = wt < nwt;
+  for (uint32_t wt = gw; wt < nwt; wt += nw) {
     const bool have_next = wt + nw < nwt;
     const uint32_t tid = opaque(threadIdx.x);
     const uint32_t lane = tid & 63, wid = tid >> 6;
     uint4* const line_l = s_line[wid];
-    uint4* const z_l = s_z[wid];
-    uint32_t* const cnt_l = reinterpret_cast<uint32_t*>(z_l);          // phase D: cnt[64] ...
-    uint32_t* const base_l = reinterpret_cast<uint32_t*>(z_l) + WT;    // ... base[64]
-    uint32_t* const oix_l = reinterpret_cast<uint32_t*>(z_l + 32);     // item -> its entry in E (64 words)
-    uint8_t* const own_l = reinterpret_cast<uint8_t*>(z_l + 48);       // item -> window * 64 + read slot (64 bytes)
+    uint32_t* const best_l = reinterpret_cast<uint32_t*>(line_l + 384);
+    uint32_t* const cnt_l = reinterpret_cast<uint32_t*>(line_l + 400);
+    uint32_t* const base_l = reinterpret_cast<uint32_t*>(line_l + 416);
+    uint32_t* const oix_l = reinterpret_cast<uint32_t*>(line_l + 432);
+    uint8_t* const own_l = reinterpret_cast<uint8_t*>(line_l + 448);
     uint3* const list_l = s_list[wid];
-    uint32_t* const best_l = s_best[wid];
 
-    // a reported candidate of any read of prev (overflow entries): prev's list / best
-    auto report_any = [&](uint32_t w, uint32_t gene, uint32_t pos) __attribute__((always_inline)) {
-      const bool rep = w != NX_REJECT && !(w & NX_DUP);
+    uint32_t nlist = 0;           // reported candidates so far (wave-uniform)
+    uint32_t best = 0xFFFFFFFFu;  // smallest mismatch count reported for this lane's read by the in-lane comparisons
+    uint32_t wc[W], oc[W], ovf[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) wc[k] = oc[k] = ovf[k] = 0;
+    const bool active = wt * WT + lane < n;
+    const int rlen = (int)REC_LEN(meta_cur);
+    const uint32_t budget = REC_BUDGET(meta_cur), valid_cur = REC_VALID(meta_cur);
+    // every read of the wave-tile of one length: the comparisons use scalar length masks
+    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(rlen);
+    const uint32_t ulen = __ballot(active && (uint32_t)rlen != len0) == 0 ? len0 : 0xFFFFFFFFu;
+
+    // a reported candidate: appended in lane order
+    auto append = [&](bool rep, uint32_t w, uint32_t gene, uint32_t pos) __attribute__((always_inline)) -> bool {
       const unsigned long long vote = __ballot(rep);
-      if (vote == 0) return;
+      if (vote == 0) return false;
       const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
-      const uint32_t slot = nlist_prev + below;
-      nlist_prev += (uint32_t)__popcll(vote);
-      if (!rep) return;
-      atomicMin(&best_l[w >> 24], w & 0xFFFFu);
+      const uint32_t slot = nlist + below;
+      nlist += (uint32_t)__popcll(vote);
+      if (!rep) return false;
       if (slot < WLIST) {
         list_l[slot] = make_uint3(w, gene, pos);
       } else if (slot - WLIST < sregion) {
         spill[sregion_w + (slot - WLIST)] = make_uint4(w, gene, pos, 0u);
       }
+      return true;
     };
-    // the accepted pairs among the items [c0, c0 + 64) go to their probes' MaxMatches counters: a probe's items
-    // are consecutive lanes (the listing is window-major, lane-major), so its owner counts the votes in its range
-    auto count_accepted = [&](unsigned long long acc_vote, uint32_t c0, const uint32_t (&pre)[W]) __attribute__((always_inline)) {
-      if (!block_mode) return;
-#pragma unroll
-      for (int kk = 0; kk < W; kk++) {
-        const uint32_t lo = pre[kk] > c0 ? pre[kk] - c0 : 0u;
-        const uint32_t hi_abs = pre[kk] + oc_prev[kk];
-        const uint32_t hi = hi_abs > c0 ? (hi_abs - c0 < 64u ? hi_abs - c0 : 64u) : 0u;
-        if (hi > lo && lo < 64u) {
-          const unsigned long long m = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-          wc_prev[kk] += (uint32_t)__popcll(acc_vote & m);
-        }
+    // ... of the lane's own read (in-lane comparisons)
+    auto report_own = [&](uint32_t w, uint32_t gene, uint32_t pos, uint32_t& wck) __attribute__((always_inline)) {
+      const bool acc = w != NX_REJECT;
+      wck += acc ? 1u : 0u;
+      if (append(acc && !(w & NX_DUP), w, gene, pos)) {
+        const uint32_t v = w & 0xFFFFu;
+        best = v < best ? v : best;
       }
     };
-    // The comparison pass over overflow entries of prev, a lane per entry: the entry's words (gene, jx, ctx[8]) from
-    // the zone, the probe it belongs to (window, read slot) and that read's meta word and record from the lane's
-    // registers.  Two windows on 120-base buckets: ONE pass with the window per lane (k_match_t's form; a hashed
-    // table needs the lane's own window exact as well: the key is not the bucket).
-    auto entry_compare = [&](uint32_t n_items, uint32_t ks, uint32_t meta, const Rec<RW>& rec, const uint4& e0, const uint4& e1, const uint4& e2,
-                             unsigned long long& acc_vote) __attribute__((always_inline)) {
-      acc_vote = 0;
+    const uint32_t rb = lane * 8u + (((lane >> 1) & 7u) ^ (lane & 1u));
+    // the part of a window that needs its lines: the header, then the three inline entries, in this lane
+    auto slots = [&](auto kc, const uint32_t (&img)[NW], const WinTab& tb) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      const int q1 = win[k];
+      const uint4 h0 = line_l[rb], h1 = line_l[rb ^ 1u];
+      const uint32_t cnt = bb_cur[k] != WB_NONE ? h0.x : 0u;  // (a probe that takes no part fetched bucket 0)
+      ncand += cnt;
+      oc[k] = cnt > (uint32_t)NIN ? cnt - (uint32_t)NIN : 0u;
+      ovf[k] = h0.y;
+      novf += oc[k];
+      uint4 ca = line_l[rb ^ 2u], cb = line_l[rb ^ 3u];
+#pragma unroll
+      for (int s = 0; s < CTX_INLINE; s++) {
+        const bool live = (uint32_t)s < cnt;
+        if (!__any(live)) break;
+        uint4 na = ca, nb = cb;
+        if (s + 1 < CTX_INLINE) {  // the next entry's context is on its way while this one is compared
+          na = line_l[rb ^ (uint32_t)(2 * s + 4)];
+          nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
+        }
+        const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
+        const uint32_t jx = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
+        const uint32_t c[NW] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+        const uint32_t w = score(live, k, q1, img, tb, jx, c, rlen, budget, valid_cur, lane);
+        report_own(w, gene, jx - (uint32_t)q1, wc[k]);
+        ca = na;
+        cb = nb;
+      }
+    };
+    // ===================================================================== F1, F2: the two windows
+    {
+      wave_lds_sync();  // (everything this wave has read from or written to its buffer is done)
+      issue_window(bb_cur[0]);
+      PF(0)
+      const uint32_t sh0 = 2u * (uint32_t)(CL - win[0]);
+      WinTab tb;
+      win_tab(ulen, 0, sh0, (uint32_t)rlen, tb);
+      uint32_t img[NW];
+      read_image_n<RW, NW>(rec_cur, sh0, img);
+      PF(1)
+      wait_vm0();
+      PF(2)
+      slots(std::integral_constant<int, 0>{}, img, tb);
+      PF(3)
+    }
+    {
+      wave_lds_sync();
+      issue_window(bb_cur[1]);
+      PF(4)
+      const uint32_t sh1 = 2u * (uint32_t)(CL - win[1]);
+      WinTab tb;
+      win_tab(ulen, 1, sh1, (uint32_t)rlen, tb);
+      uint32_t img[NW];
+      read_image_n<RW, NW>(rec_cur, sh1, img);
+      wait_vm0();
+      PF(5)
+      slots(std::integral_constant<int, 1>{}, img, tb);
+      PF(6)
+    }
+    // ===================================================================== F3: overflow entries, the next records
+    // the entries beyond the buckets' third: a lane per entry, listed window-major, lane-major
+    uint32_t pre[W], total = 0;
+#pragma unroll
+    for (int kk = 0; kk < W; kk++) {
+      const uint32_t inc = wave_scan_incl(oc[kk]);
+      pre[kk] = total + inc - oc[kk];
+      total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    // items [c0, c0 + 64): item -> (window, read slot) and its place in E, from the lanes that own the probes
+    auto owner_tables = [&](uint32_t c0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kk = 0; kk < W; kk++) {
+        const uint32_t e_lo = c0 > pre[kk] ? c0 - pre[kk] : 0u;
+        const uint32_t e_hi = pre[kk] + oc[kk] > c0 + WT ? (c0 + WT > pre[kk] ? c0 + WT - pre[kk] : 0u) : oc[kk];
+#pragma unroll 1
+        for (uint32_t e = e_lo; e < e_hi; e++) {
+          own_l[pre[kk] + e - c0] = (uint8_t)(kk * WT + lane);
+          oix_l[pre[kk] + e - c0] = ovf[kk] + e;
+        }
+      }
+      wave_lds_sync();
+    };
+    // three LDS-DMA instructions: the entries of the lanes' items -> planes 0 .. 2 of the buffer (entry 0 for a lane without an item)
+    auto issue_entries = [&](uint32_t eix) __attribute__((always_inline)) {
+      const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + ctx_entry_word<false>(eix);
+      const uint32_t zb = lds_addr(line_l);
+      glds16(pe, zb);
+      glds16(pe + 4, zb + 1024u);
+      glds16(pe + 8, zb + 2048u);
+    };
+    // The comparison pass over overflow entries, a lane per entry: the entry's words (gene, jx, ctx[8]) from the buffer,
+    // the probe it belongs to (window, read slot) and that read's meta word and record from the lane that owns the read
+    // (ds_bpermute).  ONE pass with the window per lane (k_match_t's form for two windows; a hashed table needs the
+    // lane's own window exact as well: the key is not the bucket).  c0 = the first item of the round.
+    auto entry_round = [&](uint32_t c0) __attribute__((always_inline)) {
+      const uint32_t n_items = total - c0 < 64u ? total - c0 : 64u;
       const bool have = lane < n_items;
-      if (!__any(have)) return;
+      const uint32_t ks = have ? (uint32_t)own_l[lane] : 0u;
+      const uint32_t seg = ks & 63u;
+      const uint4 e0 = line_l[lane], e1 = line_l[64 + lane], e2 = line_l[128 + lane];
+      const uint32_t meta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(seg * 4u), (int)meta_cur);
+      Rec<RW> rec;
+#pragma unroll
+      for (int q = 0; q < RW; q++) rec.w[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(seg * 4u), (int)rec_cur.w[q]);
       const int len = (int)REC_LEN(meta);
       const uint32_t gene = e0.x, jx = e0.y;
       const uint32_t c[NW] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y};
-      const uint32_t seg = ks & 63u;
       const bool k1 = have && (ks >> 6) != 0;
       const int q1a = win[0], q1b = win[1];
       const uint32_t sha = 2u * (uint32_t)(CL - q1a), shb = 2u * (uint32_t)(CL - q1b);
       const uint32_t sh = k1 ? shb : sha;
       const int q1 = k1 ? q1b : q1a;
       uint32_t lm[NW];
-      if (ulen_prev != 0xFFFFFFFFu) {
-        const uint32_t (*rows)[CTXW_WORDS] = mp->lm[__builtin_amdgcn_readfirstlane((int)ulen_prev)];
+      if (ulen != 0xFFFFFFFFu) {
+        const uint32_t (*rows)[CTXW_WORDS] = mp->lm[__builtin_amdgcn_readfirstlane((int)ulen)];
 #pragma unroll
         for (int j = 0; j < NW; j++) lm[j] = k1 ? rows[1][j] : rows[0][j];
       } else {
@@ -421,77 +518,106 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
           w = (first ? nx : (nx | NX_DUP)) | NX_ACC0 | (k1 ? 1u << 20 : 0u) | (seg << 24);
         }
       }
-      acc_vote = __ballot(w != NX_REJECT);
-      report_any(w, gene, jx - (uint32_t)q1);
-    };
-    // the items [c0, c0 + 64) of prev: item -> (window, read slot) and its place in E, from the lanes that own the probes
-    auto owner_tables = [&](uint32_t c0, const uint32_t (&oc)[W], const uint32_t (&ovf)[W], const uint32_t (&pre)[W]) __attribute__((always_inline)) {
+      // the accepted pairs go to their probes' MaxMatches counters: a probe's items are consecutive lanes, so its
+      // owner counts the votes in its range
+      if (block_mode) {
+        const unsigned long long acc_vote = __ballot(w != NX_REJECT);
 #pragma unroll
-      for (int kk = 0; kk < W; kk++) {
-        const uint32_t e_lo = c0 > pre[kk] ? c0 - pre[kk] : 0u;
-        const uint32_t e_hi = pre[kk] + oc[kk] > c0 + WT ? (c0 + WT > pre[kk] ? c0 + WT - pre[kk] : 0u) : oc[kk];
-#pragma unroll 1
-        for (uint32_t e = e_lo; e < e_hi; e++) {
-          own_l[pre[kk] + e - c0] = (uint8_t)(kk * WT + lane);
-          oix_l[pre[kk] + e - c0] = ovf[kk] + e;
+        for (int kk = 0; kk < W; kk++) {
+          const uint32_t lo = pre[kk] > c0 ? pre[kk] - c0 : 0u;
+          const uint32_t hi_abs = pre[kk] + oc[kk];
+          const uint32_t hi = hi_abs > c0 ? (hi_abs - c0 < 64u ? hi_abs - c0 : 64u) : 0u;
+          if (hi > lo && lo < 64u) {
+            const unsigned long long m = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            wc[kk] += (uint32_t)__popcll(acc_vote & m);
+          }
         }
       }
-      wave_lds_sync();
+      if (append(w != NX_REJECT && !(w & NX_DUP), w, gene, jx - (uint32_t)q1)) atomicMin(&best_l[seg], w & 0xFFFFu);
     };
-    // three LDS-DMA instructions: the entries of the lanes' items -> the zone (lanes 0 .. ZI - 1; entry 0 for a lane without an item)
-    auto issue_entries = [&](uint32_t eix) __attribute__((always_inline)) {
-      if (lane < ZI) {
-        const uint32_t* __restrict__ pe = reinterpret_cast<const uint32_t*>(E) + ctx_entry_word<false>(eix);
-        const uint32_t zb = lds_addr(z_l);
-        glds16(pe, zb);
-        glds16(pe + 4, zb + 16u * ZI);
-        glds16(pe + 8, zb + 32u * ZI);
-      }
-    };
-    // prev's overflow entries beyond the first ZI (families of near-identical targets, low-complexity keys): listed,
-    // fetched and compared on the spot, ZI at a time -- every round a memory round trip of its own, and the flight
-    // of cur's window 0 ends with the first of them.  The reads' records come from global memory.
-    auto overflow_rest_prev = [&](const uint32_t (&pre)[W]) __attribute__((always_inline)) {
-      for (uint32_t c0 = ZI; c0 < total_prev; c0 += ZI) {
+    Rec<RW> rec_nx;
+    rec_nx.zero();
+    {
+      wave_lds_sync();  // (every lane has read its line of window 1)
+      best_l[lane] = 0xFFFFFFFFu;
+      uint32_t eix = 0;
+      if (total) {
+        owner_tables(0);
+        eix = lane < total ? oix_l[lane] : 0u;
         wave_lds_sync();
-        owner_tables(c0, oc_prev, ovf_prev, pre);
-        const uint32_t cnt = total_prev - c0 < ZI ? total_prev - c0 : ZI;
-        const bool mine = lane < cnt;
-        const uint32_t ks = mine ? (uint32_t)own_l[lane] : 0u;
-        const uint32_t eix = mine ? oix_l[lane] : 0u;
-        const uint32_t tmeta = s_meta[wid][ks & 63u];
-        wave_lds_sync();  // (the tables are read: the entries may land on them)
         issue_entries(eix);
-        Rec<RW> trec;
-        trec.load(rd + (r0 + (uint64_t)wt_prev * WT + (ks & 63u)) * (uint64_t)RW, RW);
-        wait_vm0();
-        const uint4 e0 = z_l[lane < ZI ? lane : 0], e1 = z_l[ZI + (lane < ZI ? lane : 0)], e2 = z_l[2 * ZI + (lane < ZI ? lane : 0)];
-        unsigned long long av;
-        entry_compare(cnt, ks, tmeta, trec, e0, e1, e2, av);
-        count_accepted(av, c0, pre);
       }
-    };
-    // phase D for prev: per-read selection and the tuples (the protocol of match_ctx_pass; k_match_t's phase D with one
-    // generation of lists)
-    auto phase_d_prev = [&]() __attribute__((always_inline)) {
-      const uint32_t nl = nlist_prev;
+      if (have_next) {
+        // the records of the next wave-tile, RW / 4 instructions of 1 KB contiguous (chunks of reads past the batch's end
+        // come from read 0)
+        const uint32_t zb = lds_addr(line_l + 256);
+#pragma unroll
+        for (int q = 0; q < RW / 4; q++) {
+          const uint32_t g = (uint32_t)q * 64u + lane;
+          const uint32_t i = (wt + nw) * WT + g / (uint32_t)(RW / 4);
+          glds16(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW + 4u * (g % (uint32_t)(RW / 4)), zb + (uint32_t)q * 1024u);
+        }
+      }
+      uint32_t cpm = 0, cpd = 0;
+      if (pcopy && wt < pnwt) {
+        const uint32_t wtu = (uint32_t)__builtin_amdgcn_readfirstlane((int)wt);
+        cpm = ptcount2[wtu];
+        cpd = ptpre[wtu];
+        if (cpm) glds16(pstage + region0 + pused + (lane < cpm ? lane : 0u), lds_addr(line_l + 192));
+      }
+      PF(7)
+      if (total || have_next || cpm) wait_vm0();
+      PF(8)
+      if (cpm) {
+        uint4* __restrict__ dst = hits + pbase + cpd;
+        if (lane < cpm) dst[lane] = line_l[192 + lane];
+        for (uint32_t i = 64 + lane; i < cpm; i += 64) dst[i] = pstage[region0 + pused + i];  // a tile with more than 64 tuples
+        pused += cpm;
+      }
+      if (have_next) {
+        const uint4* src = line_l + 256 + lane * (RW / 4);
+#pragma unroll
+        for (int q = 0; q < RW / 4; q++) {
+          const uint4 v = src[q];
+          rec_nx.w[4 * q] = v.x; rec_nx.w[4 * q + 1] = v.y; rec_nx.w[4 * q + 2] = v.z; rec_nx.w[4 * q + 3] = v.w;
+        }
+      }
+      if (total) {
+        entry_round(0);
+        // beyond the first 64 (families of near-identical targets, low-complexity keys): listed, fetched and compared on
+        // the spot, 64 at a time -- every round a memory round trip of its own
+        for (uint32_t c0 = 64; c0 < total; c0 += 64) {
+          wave_lds_sync();
+          owner_tables(c0);
+          const uint32_t e2 = lane < total - c0 ? oix_l[lane] : 0u;
+          wave_lds_sync();
+          issue_entries(e2);
+          wait_vm0();
+          entry_round(c0);
+        }
+      }
+      PF(9)
+    }
+    // ===================================================================== phase D: per-read selection, the tuples
+    {
+      const uint32_t nl = nlist;
       const uint32_t nspill = nl > WLIST ? nl - WLIST : 0u;
       const bool spill_ok = nspill <= sregion;
       if (nspill > maxspill) maxspill = nspill;
-      if (nspill) wait_vm0();  // this wave's spilled candidates have landed (and cur's window 0: a heavy tile pays for it)
+      if (nspill) wait_vm0();  // this wave's spilled candidates have landed
       if (block_mode) {
 #pragma unroll
         for (int k = 0; k < W; k++) {
-          const uint32_t cw = wc_prev[k];
+          const uint32_t cw = wc[k];
           if (!cw) continue;
-          const uint32_t h = block_hash32((uint32_t)k, bb_prev[k]);
-          if (block_mode == 1) atomicAdd(&s_sketch[h >> (32 - MATCH_SKETCH_BITS)], cw);
+          const uint32_t h = block_hash32((uint32_t)k, bb_cur[k]);
+          if (block_mode == 1) atomicAdd(&s_sketch[h >> (32 - MATCHG_SKETCH_BITS)], cw);
           else atomicAdd(&block_table[h >> (32 - BLOCK_TABLE_BITS)], cw);
         }
       }
       {
         const uint32_t b0 = best_l[lane];
-        best_l[lane] = best_prev < b0 ? best_prev : b0;
+        best_l[lane] = best < b0 ? best : b0;
       }
       cnt_l[lane] = 0;
       wave_lds_sync();
@@ -502,6 +628,7 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
           *pos = it.z;
           return it.x;
         }
+        // written by other lanes of this wave a moment ago: read past the L1
         const uint32_t* sp = reinterpret_cast<const uint32_t*>(spill + sregion_w + (j - WLIST));
         *gene = __hip_atomic_load(sp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *pos = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -509,7 +636,7 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
       };
       const uint32_t nuse = spill_ok ? nl : (nl < WLIST ? nl : WLIST);
       // the first round of candidates (a lane each; cfg3 has ~53 per wave-tile) stays in registers from the count to
-      // the store; further rounds are walked twice
+      // the store: the counting atomic also hands out the tuple's place among its read's; further rounds are walked twice
       uint32_t kw = NX_REJECT, kg = 0, kp = 0, ko = 0;
       if (lane < nuse) {
         const uint32_t w = item(lane, &kg, &kp);
@@ -530,19 +657,19 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
       wave_lds_sync();
       const uint32_t cnum = cnt_l[lane];
       const uint32_t inc = wave_scan_incl(cnum);
-      const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
+      const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
       base_l[lane] = inc - cnum;
       const uint64_t base = region0 + used;
-      const bool fits = spill_ok && used + total <= region;
+      const bool fits = spill_ok && used + tot <= region;
       if (lane == 0) {
-        tbase[wt_prev] = (uint32_t)base;
-        tcount2[wt_prev] = fits ? total : 0u;
+        tbase[wt] = (uint32_t)base;
+        tcount2[wt] = fits ? tot : 0u;
       }
       wave_lds_sync();
-      if (fits && total) {
+      if (fits && tot) {
         if (kw != NX_REJECT) {
           const uint32_t rl = kw >> 24;
-          stage[base + base_l[rl] + ko] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), kg, kp, kw & 0xFFFFu);
+          stage[base + base_l[rl] + ko] = make_uint4((uint32_t)(r0 + wt * WT + rl), kg, kp, kw & 0xFFFFu);
         }
         if (nuse > 64) {
           for (uint32_t j = 64 + lane; j < nuse; j += 64) {
@@ -551,213 +678,42 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
             const uint32_t rl = w >> 24, v = w & 0xFFFFu;
             const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
             if (v > thr) continue;
+            // places of the later rounds: behind the first round's tuples of the read, counted down from its total
             const uint32_t ord = atomicAdd(&cnt_l[rl], 0xFFFFFFFFu) - 1u;
-            stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), g, p, v);
+            stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt * WT + rl), g, p, v);
           }
         }
       }
-      wave_lds_sync();
-      best_l[lane] = 0xFFFFFFFFu;  // for cur
-      used += total;
+      used += tot;
       nrep += lane == 0 ? nl : 0u;
-    };
-
-    // ===================================================================== F1
-    // this lane's item of prev (tables in the zone, written when prev's last window was compared): read BEFORE the
-    // entries land on them
-    const bool ent = have_prev && o_n > 0;
-    wave_lds_sync();  // (everything this wave has read from or written to the zone and the line buffer is done)
-    if (ent) issue_entries(o_eix);
-    if (have_cur) issue_window(bb_cur[0]);
-    PF(0)
-    uint32_t nlist = 0;           // reported candidates of cur so far (wave-uniform)
-    uint32_t best = 0xFFFFFFFFu;  // smallest mismatch count reported for this lane's read by the in-lane comparisons
-    uint32_t ulen = 0xFFFFFFFFu, total_cur = 0;
-    uint32_t wc[W], oc[W], ovf[W];
-    uint32_t meta_nx = 0, bb_nx[W];
-    Rec<RW> rec_nx;
-    rec_nx.zero();
-#pragma unroll
-    for (int k = 0; k < W; k++) wc[k] = oc[k] = ovf[k] = 0, bb_nx[k] = WB_NONE;
-    if (have_prev) {
-      uint32_t pre[W], total = 0;
-#pragma unroll
-      for (int kk = 0; kk < W; kk++) {
-        const uint32_t inc = wave_scan_incl(oc_prev[kk]);
-        pre[kk] = total + inc - oc_prev[kk];
-        total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-      }
-      if (ent) {
-        if (have_cur) wait_vm8();  // the entries are there; the eight line instructions behind them still fly
-        else wait_vm0();
-        const uint32_t li = lane < ZI ? lane : 0u;
-        const uint4 e0 = z_l[li], e1 = z_l[ZI + li], e2 = z_l[2 * ZI + li];
-        unsigned long long av;
-        entry_compare(o_n, o_ks, o_meta, o_rec, e0, e1, e2, av);
-        count_accepted(av, 0, pre);
-        PF(1)
-        if (total_prev > ZI) overflow_rest_prev(pre);
-      }
-      wave_lds_sync();
-      phase_d_prev();
-      PF(2)
+      PF(10)
     }
-    if (have_cur) {
-      const bool active = wt * WT + lane < n;
-      const int rlen = (int)REC_LEN(meta_cur);
-      const uint32_t budget = REC_BUDGET(meta_cur), valid_cur = REC_VALID(meta_cur);
-      s_meta[wid][lane] = meta_cur;
-      const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(rlen);
-      ulen = __ballot(active && (uint32_t)rlen != len0) == 0 ? len0 : 0xFFFFFFFFu;
-
-      // a reported candidate of the lane's own read (in-lane comparisons): appended in lane order
-      auto report_own = [&](uint32_t w, uint32_t gene, uint32_t pos, uint32_t& wck) __attribute__((always_inline)) {
-        const bool acc = w != NX_REJECT;
-        wck += acc ? 1u : 0u;
-        const bool rep = acc && !(w & NX_DUP);
-        const unsigned long long vote = __ballot(rep);
-        if (vote == 0) return;
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
-        const uint32_t slot = nlist + below;
-        nlist += (uint32_t)__popcll(vote);
-        if (!rep) return;
-        const uint32_t v = w & 0xFFFFu;
-        best = v < best ? v : best;
-        if (slot < WLIST) {
-          list_l[slot] = make_uint3(w, gene, pos);
-        } else if (slot - WLIST < sregion) {
-          spill[sregion_w + (slot - WLIST)] = make_uint4(w, gene, pos, 0u);
-        }
-      };
-      const uint32_t rb = lane * 8u + (((lane >> 1) & 7u) ^ (lane & 1u));
-      // the part of a window that needs its lines: the header, then the three inline entries, in this lane
-      auto slots = [&](auto kc, const uint32_t (&img)[NW], const WinTab& tb) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        const int q1 = win[k];
-        const uint4 h0 = line_l[rb], h1 = line_l[rb ^ 1u];
-        const uint32_t cnt = bb_cur[k] != WB_NONE ? h0.x : 0u;  // (a probe that takes no part fetched bucket 0)
-        ncand += cnt;
-        oc[k] = cnt > (uint32_t)NIN ? cnt - (uint32_t)NIN : 0u;
-        ovf[k] = h0.y;
-        novf += oc[k];
-        uint4 ca = line_l[rb ^ 2u], cb = line_l[rb ^ 3u];
-#pragma unroll
-        for (int s = 0; s < CTX_INLINE; s++) {
-          const bool live = (uint32_t)s < cnt;
-          if (!__any(live)) break;
-          uint4 na = ca, nb = cb;
-          if (s + 1 < CTX_INLINE) {  // the next entry's context is on its way while this one is compared
-            na = line_l[rb ^ (uint32_t)(2 * s + 4)];
-            nb = line_l[rb ^ (uint32_t)(2 * s + 5)];
-          }
-          const uint32_t gene = s == 0 ? h0.z : (s == 1 ? h0.w : h1.x);
-          const uint32_t jx = s == 0 ? h1.y : (s == 1 ? h1.z : h1.w);
-          const uint32_t c[NW] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
-          const uint32_t w = score(live, k, q1, img, tb, jx, c, rlen, budget, valid_cur, lane);
-          report_own(w, gene, jx - (uint32_t)q1, wc[k]);
-          ca = na;
-          cb = nb;
-        }
-      };
-      {
-        // ---- window 0: its image and tables while its lines fly
-        const uint32_t sh0 = 2u * (uint32_t)(CL - win[0]);
-        WinTab tb;
-        win_tab(ulen, 0, sh0, (uint32_t)rlen, tb);
-        uint32_t img[NW];
-        read_image_n<RW, NW>(rec_cur, sh0, img);
-        PF(3)
-        wait_vm0();
-        PF(4)
-        slots(std::integral_constant<int, 0>{}, img, tb);
-        PF(5)
-      }
-      // ================================================================= F2
-      wave_lds_sync();  // (the lane has read its line of window 0; the zone's last readers were phase D / the entries)
-      issue_window(bb_cur[1]);
-      if (have_next) {
-        // the records of the next wave-tile, RW / 4 instructions of 1 KB contiguous (chunks of reads past the batch's end
-        // come from read 0), into the zone
-        const uint32_t zb = lds_addr(z_l);
-#pragma unroll
-        for (int q = 0; q < RW / 4; q++) {
-          const uint32_t g = (uint32_t)q * 64u + lane;
-          const uint32_t i = (wt + nw) * WT + g / (uint32_t)(RW / 4);
-          glds16(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW + 4u * (g % (uint32_t)(RW / 4)), zb + (uint32_t)q * 1024u);
-        }
-      }
-      PF(6)
-      {
-        const uint32_t sh1 = 2u * (uint32_t)(CL - win[1]);
-        WinTab tb;
-        win_tab(ulen, 1, sh1, (uint32_t)rlen, tb);
-        uint32_t img[NW];
-        read_image_n<RW, NW>(rec_cur, sh1, img);
-        PF(7)
-        wait_vm0();
-        PF(8)
-        if (have_next) {
-          // the next wave-tile's records -> registers, its phase A
-          const uint4* src = z_l + lane * (RW / 4);
-#pragma unroll
-          for (int q = 0; q < RW / 4; q++) {
-            const uint4 v = src[q];
-            rec_nx.w[4 * q] = v.x; rec_nx.w[4 * q + 1] = v.y; rec_nx.w[4 * q + 2] = v.z; rec_nx.w[4 * q + 3] = v.w;
-          }
-          meta_nx = phase_a(wt + nw, rec_nx, bb_nx);
-        }
-        PF(9)
-        slots(std::integral_constant<int, 1>{}, img, tb);
-        PF(10)
-      }
-      // ---- this wave-tile's overflow entries: the first ZI are listed (item tables -> the zone, which the next
-      // wave-tile's records have left) and their lanes take the reads' meta words and records along
-      {
-        uint32_t pre[W], total = 0;
-#pragma unroll
-        for (int kk = 0; kk < W; kk++) {
-          const uint32_t inc = wave_scan_incl(oc[kk]);
-          pre[kk] = total + inc - oc[kk];
-          total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        }
-        total_cur = total;
-        wave_lds_sync();
-        owner_tables(0, oc, ovf, pre);
-        o_n = total < ZI ? total : ZI;
-        const bool mine = lane < o_n;
-        o_ks = mine ? (uint32_t)own_l[lane] : 0u;
-        o_eix = mine ? oix_l[lane] : 0u;
-        o_meta = s_meta[wid][o_ks & 63u];
-        // the item's read's record: from the lane that owns the read (the LDS crossbar, no memory)
-#pragma unroll
-        for (int q = 0; q < RW; q++) o_rec.w[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((o_ks & 63u) * 4u), (int)rec_cur.w[q]);
-      }
-      PF(11)
-#ifdef MUSC_LANE_PROF
-      pf_tiles++;
-#endif
-    }
-    // ---- cur becomes prev
-    have_prev = have_cur;
-    if (have_cur) {
-      wt_prev = wt;
-      nlist_prev = nlist;
-      best_prev = best;
-      ulen_prev = ulen;
-      total_prev = total_cur;
-#pragma unroll
-      for (int k = 0; k < W; k++) wc_prev[k] = wc[k], bb_prev[k] = bb_cur[k], bb_cur[k] = bb_nx[k], oc_prev[k] = oc[k], ovf_prev[k] = ovf[k];
-      meta_cur = meta_nx;
+    // ---- the next wave-tile's phase A; its record, buckets and meta word become the ones in hand
+    if (have_next) {
+      meta_cur = phase_a(wt + nw, rec_nx, bb_cur);
       rec_cur = rec_nx;
-      wt += nw;
     }
+    PF(11)
+#ifdef MUSC_LANE_PROF
+    pf_tiles++;
+#endif
   }
 #ifdef MUSC_LANE_PROF
   if ((gw == 0 || gw == 1001) && (threadIdx.x & 63) == 0 && pf_tiles > 4)
-    printf("wave %u: %u tiles, cycles/tile: total %llu | F1 issue %llu ovf compare %llu phase D %llu image0 %llu wait0 %llu slots0 %llu | F2 issue %llu image1 %llu wait1 %llu phase A next %llu slots1 %llu listing %llu\n",
+    printf("wave %u: %u tiles, cycles/tile: total %llu | F1 issue %llu image0 %llu wait0 %llu slots0 %llu | F2 issue %llu image1+wait1 %llu slots1 %llu | F3 list+issue %llu wait %llu entries %llu | phase D %llu phase A next %llu\n",
            gw, pf_tiles, (__builtin_amdgcn_s_memtime() - pstart) / pf_tiles, pf[0] / pf_tiles, pf[1] / pf_tiles, pf[2] / pf_tiles, pf[3] / pf_tiles,
            pf[4] / pf_tiles, pf[5] / pf_tiles, pf[6] / pf_tiles, pf[7] / pf_tiles, pf[8] / pf_tiles, pf[9] / pf_tiles, pf[10] / pf_tiles, pf[11] / pf_tiles);
 #endif
+  if (pcopy) {
+    const uint32_t mine = gw < nwt ? (nwt - gw + nw - 1) / nw : 0u;  // wave-tiles of this batch this wave has walked
+    for (uint32_t wt = gw + mine * nw; wt < pnwt; wt += nw) {
+      const uint32_t wtu = (uint32_t)__builtin_amdgcn_readfirstlane((int)wt);
+      const uint32_t m = ptcount2[wtu], d = ptpre[wtu];
+      const uint32_t lane = opaque(threadIdx.x) & 63;
+      for (uint32_t i = lane; i < m; i += 64) hits[pbase + d + i] = pstage[region0 + pused + i];
+      pused += m;
+    }
+  }
   // one reduction per workgroup and a handful of atomics from its first thread (as in k_match_t)
   {
     __shared__ unsigned long long s_red[NWAVE][8];
@@ -798,7 +754,7 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
   if (block_mode == 1) {
     __syncthreads();
     uint32_t hot = 0;
-    for (uint32_t t = threadIdx.x; t < (1u << MATCH_SKETCH_BITS); t += TILE) hot |= s_sketch[t] >= block_thr;
+    for (uint32_t t = threadIdx.x; t < (1u << MATCHG_SKETCH_BITS); t += TILE) hot |= s_sketch[t] >= block_thr;
     if (__any(hot) && (threadIdx.x & 63) == 0) atomicOr(&counters[6], 1ull);
   }
 }

@@ -45,14 +45,19 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
                                                                 const uint32_t* __restrict__ rdx);
 // k_match_g (kernels_match_dma.hpp): the same kernel at three waves per SIMD -- lines, overflow entries and records by
 // LDS-DMA -- for two windows on 120-base buckets without X (BASELINE configs 2-4); general (SG = 0) and specialised
-#ifndef MATCHG_WAVES
-#define MATCHG_WAVES 3
+// waves per SIMD the register allocator leaves room for: four (128 VGPRs) for a geometry-specialised instance, three
+// (168) for the general one, which would spill four registers into scratch at 128; LDS allows four either way
+#ifndef MATCHG_WAVES_OF
+#define MATCHG_WAVES_OF(SG) ((SG) ? 4 : 3)
+#endif
+#ifndef MATCHG_SKETCH_BITS
+#define MATCHG_SKETCH_BITS 9  // cells of the workgroup's MaxMatches sketch (2 KB: four workgroups of 38 KB fit a CU)
 #endif
 #ifndef MATCHG_WLIST
 #define MATCHG_WLIST 64  // reported candidates of a wave-tile kept in LDS (cfg3: ~53); more spill to HBM
 #endif
 template <int RW, int SG>
-__global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
+__global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
                                                                 const uint16_t* __restrict__ nmiss_tab,
                                                                 const CtxBucket* __restrict__ T, const CtxEntry* __restrict__ E,
@@ -61,10 +66,15 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES) void k_match_g(const uint32_t* 
                                                                 uint32_t* __restrict__ tbase, uint32_t* __restrict__ tcount2,
                                                                 int block_mode, uint32_t block_thr,
                                                                 uint32_t* __restrict__ block_table,
-                                                                unsigned long long* __restrict__ counters);
+                                                                unsigned long long* __restrict__ counters,
+                                                                const uint4* __restrict__ pstage, const uint32_t* __restrict__ ptcount2,
+                                                                const uint32_t* __restrict__ ptpre, uint32_t pnwt,
+                                                                uint4* __restrict__ hits, uint64_t hits_cap,
+                                                                const uint32_t* __restrict__ rdx);
 #define MUSC_DMA_ARGS                                                                                                  \
   (const uint32_t*, uint64_t, uint32_t, const MatchParams*, const uint16_t*, const CtxBucket*, const CtxEntry*, uint4*, \
-   uint64_t, uint4*, uint64_t, uint32_t*, uint32_t*, int, uint32_t, uint32_t*, unsigned long long*)
+   uint64_t, uint4*, uint64_t, uint32_t*, uint32_t*, int, uint32_t, uint32_t*, unsigned long long*, const uint4*,   \
+   const uint32_t*, const uint32_t*, uint32_t, uint4*, uint64_t, const uint32_t*)
 #define MUSC_DMA_INSTANCES(X)                            \
   X template __global__ void k_match_g<8, 0> MUSC_DMA_ARGS; \
   X template __global__ void k_match_g<8, 1> MUSC_DMA_ARGS;

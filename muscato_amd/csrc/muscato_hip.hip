@@ -158,8 +158,7 @@ struct TmpBufs {
 struct EnvKnobs {
   enum { IDX_AUTO = 0, IDX_CLASSIC, IDX_LINES, IDX_CLASSIC64 };
   int index = IDX_AUTO;       // MUSC_INDEX = classic | lines | classic64: the two-kernel path (on that bucket layout)
-  bool match_quad = false;    // MUSC_MATCH = quad: k_match instead of k_match_t
-  bool match_lane = false;    // MUSC_MATCH = lane: k_match_t where the LDS-DMA kernel would run
+  bool match_dma = false;     // MUSC_MATCH = dma: k_match_g (kernels_match_dma.hpp) where it is built for the run, k_match_t elsewhere
   bool screen_wg = false;     // MUSC_SCREEN = wg: k_screen on line buckets instead of k_screen_t
   int context = 0;            // MUSC_CONTEXT = narrow (1) | wide (2)
   bool no_x_context = false;  // MUSC_NO_X_CONTEXT
@@ -178,8 +177,7 @@ struct EnvKnobs {
     const char* e = getenv("MUSC_INDEX");
     index = is(e, "classic") ? IDX_CLASSIC : is(e, "lines") ? IDX_LINES : is(e, "classic64") ? IDX_CLASSIC64 : IDX_AUTO;
     e = getenv("MUSC_MATCH");
-    match_quad = is(e, "quad");
-    match_lane = is(e, "lane");
+    match_dma = is(e, "dma");
     screen_wg = is(getenv("MUSC_SCREEN"), "wg");
     e = getenv("MUSC_CONTEXT");
     context = is(e, "narrow") ? 1 : is(e, "wide") ? 2 : 0;
@@ -1084,16 +1082,15 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
   return 0;
 }
 
-// Which of the kernels on context buckets runs: k_match_t (comparisons in the lane that owns the read,
-// kernels_match_lane.hpp); MUSC_MATCH=quad selects k_match (comparison where the line arrives), the
-// first fused kernel, kept as a second implementation the tests run everything through as well.
-enum MatchKind { MK_QUAD = 0, MK_LANE = 2, MK_DMA = 3 };
-// MK_DMA = k_match_g (kernels_match_dma.hpp): k_match_t's comparisons at three waves per SIMD, everything from memory by
-// LDS-DMA -- built for two windows on 120-base buckets, records of 8 words, no X on either side (BASELINE configs
-// 2-4); MUSC_MATCH=lane keeps such runs on k_match_t (A/B runs, and the parity tests run both)
+// Which of the two fused kernels on context buckets runs
+enum MatchKind { MK_LANE = 2, MK_DMA = 3 };
+// MK_LANE = k_match_t (kernels_match_lane.hpp): every run on context buckets.  MK_DMA = k_match_g
+// (kernels_match_dma.hpp): the same comparisons at three to four waves per SIMD, everything from memory by LDS-DMA --
+// built for two windows on 120-base buckets, records of 8 words, no X on either side (BASELINE configs 2-4).  It is
+// the second implementation (MUSC_MATCH=dma; the parity tests run both): on cfg3 its launch takes as long as
+// k_match_t's.
 static int match_kind(const musc_ctx* c, int W) {
-  if (c->env.match_quad) return MK_QUAD;
-  if (!c->env.match_lane && W == 2 && c->rw == 8 && c->idx_kind == 1 && !c->idx_wide && !c->db_has_x && !c->reads_have_x) return MK_DMA;
+  if (c->env.match_dma && W == 2 && c->rw == 8 && c->idx_kind == 1 && !c->idx_wide && !c->db_has_x && !c->reads_have_x) return MK_DMA;
   return MK_LANE;
 }
 
@@ -1184,7 +1181,7 @@ static bool ctx_eligible(musc_ctx* c, const musc_params* P, uint32_t max_len, in
   if (c->env.index != EnvKnobs::IDX_AUTO) return false;  // the two-kernel path
   // (the planes themselves may exist without an X: an all-zero one is made for the side that has
   // none when the other side does, and the database's stays for the context's lifetime)
-  const bool lane = match_kind(c, P->n_windows) != MK_QUAD;
+  const bool lane = true;  // (both fused kernels read flagged entries, xpos words and wide buckets' runs: k_match_g only takes runs without them)
   // a database with X: k_match_t only (an entry whose context holds an X is flagged in bit 31 of its
   // position, the X's place or "several: see the mask plane" in the top byte of its target number)
   if (c->db_has_x && (!lane || c->max_tlen >= 0x80000000ull || c->nseq > (1u << 24) || c->env.no_x_context)) return false;
@@ -1450,7 +1447,7 @@ int musc_reads_load_packed(musc_ctx* c, const uint8_t* bases2bit, const uint8_t*
 extern "C++" {
 static size_t match_dyn_lds(int kind, int W, int block_mode) {
   // per-(window, read) counters of the wave-tile in hand (k_match_t: of two wave-tiles), then (mode 1) the sketch
-  if (kind == MK_DMA) return block_mode == 1 ? (size_t)(4u << MATCH_SKETCH_BITS) : 0u;  // (its per-(window, read) counters are registers)
+  if (kind == MK_DMA) return block_mode == 1 ? (size_t)(4u << MATCHG_SKETCH_BITS) : 0u;  // (its per-(window, read) counters are registers)
   const size_t wcnt = (size_t)TILE * W * 4 * (kind == MK_LANE ? 2 : 1);  // TILE = 4 waves x 64
   return block_mode ? wcnt + (block_mode == 1 ? (4u << MATCH_SKETCH_BITS) : 0u) : 0u;
 }
@@ -1483,9 +1480,7 @@ static const void* match_fn(const musc_ctx* c, int W) {
 #undef MUSC_LANE_FN
 #undef MUSC_LANE_FN2
   }
-  if constexpr (RW > 12) return nullptr;
-  else
-  return W <= 2 ? reinterpret_cast<const void*>(&k_match<RW, true>) : reinterpret_cast<const void*>(&k_match<RW, false>);
+  return nullptr;
 }
 
 // workgroups of the kernel that are resident at once on this device: the persistent grid
@@ -1530,19 +1525,19 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
   hipLaunchKernelGGL(K, grid, block, lds, c->stream, c->rd, r0, n, c->d_mp, c->nmiss_tab.p,                       \
                      c->ctx_T, c->ctx_E, st.p, c->stage.cap, c->spill.p, c->spill.cap, c->bs[0].tbase.p,          \
                      tc.p, block_mode, block_thr, c->block_table.p, c->counters, ##__VA_ARGS__)
-  if (kind == MK_DMA) {
-    if constexpr (RW == 8) {
-      if (c->spec_geom == 1) MUSC_LAUNCH_MATCH((k_match_g<8, 1>));
-      else MUSC_LAUNCH_MATCH((k_match_g<8, 0>));
-    }
-    return;
-  }
-  if (kind != MK_QUAD) {
+  {
     const uint4* pst = prev_tiles ? (set ? c->stage.p : c->stage_b.p) : nullptr;
     const uint32_t* ptc = set ? c->tcount2.p : c->tcount2_b.p;
     const uint32_t* ptp = set ? c->tpre.p : c->tpre_b.p;
     uint4* const hp = reinterpret_cast<uint4*>(c->hits.p);
     const uint32_t* const rdx = c->reads_have_x ? (const uint32_t*)c->rdx.p : (const uint32_t*)nullptr;
+    if (kind == MK_DMA) {
+      if constexpr (RW == 8) {
+        if (c->spec_geom == 1) MUSC_LAUNCH_MATCH((k_match_g<8, 1>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx);
+        else MUSC_LAUNCH_MATCH((k_match_g<8, 0>), pst, ptc, ptp, prev_tiles, hp, c->hits.cap, rdx);
+      }
+      return;
+    }
     if (kind == MK_LANE) {
       if constexpr (RW == 8) {
         if (c->spec_geom == 1) {  // (chosen by spec_geom_matches: every specialised quantity equals the run's)
@@ -1570,9 +1565,6 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
       return;
     }
   }
-  if constexpr (RW <= 12) {
-    if (W <= 2) MUSC_LAUNCH_MATCH((k_match<RW, true>)); else MUSC_LAUNCH_MATCH((k_match<RW, false>));
-  }
 #undef MUSC_LAUNCH_MATCH
 }
 }  // extern "C++"
@@ -1594,7 +1586,7 @@ static bool spec_geom_equals(const MatchParams& mp) {
 }
 }  // extern "C++"
 static int spec_geom_matches(const musc_ctx* c, const MatchParams& mp) {
-  if (c->env.no_spec || c->env.match_quad) return 0;
+  if (c->env.no_spec) return 0;
   if (c->rw != 8 || c->idx_wide || c->db_has_x || c->reads_have_x) return 0;  // the instances that exist: <8, 2, 0, false, g>
   if (spec_geom_equals<1>(mp)) return 1;
   return 0;
@@ -1605,7 +1597,6 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
   int rc = 0;
   if (c->rw != 4 && c->rw != 8 && c->rw != 12 && !(c->rw == 16 && c->idx_wide))
     return fail(c, 12, "internal: record stride %d on the context path", c->rw);
-  if (c->idx_wide && match_kind(c, pp.W) == MK_QUAD) return fail(c, 12, "internal: wide context buckets need k_match_t");
   (void)block_thr_unused;
   // the run's parameter block (and with it the kernel instance: match_fn looks at c->spec_geom)
   {
@@ -1619,7 +1610,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     for (int k = 0; k < pp.W && k < CTX_MAX_W; k++) mp.win[k] = pp.win[k];
     match_tables(mp);
     c->spec_geom = spec_geom_matches(c, mp);
-    c->stats.match_variant = match_kind(c, pp.W) == MK_QUAD ? 1u : (match_kind(c, pp.W) == MK_DMA ? 4u : 2u) + (c->spec_geom ? 1u : 0u);
+    c->stats.match_variant = (match_kind(c, pp.W) == MK_DMA ? 4u : 2u) + (c->spec_geom ? 1u : 0u);
     if (!c->h_mp_valid || memcmp(&mp, &c->h_mp, sizeof mp) != 0) {
       c->h_mp = mp;
       HIPCHK(c, hipMemcpyAsync(c->d_mp, &c->h_mp, sizeof mp, hipMemcpyHostToDevice, c->stream));
@@ -1653,7 +1644,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
   }
-  const bool fuse_ok = match_kind(c, pp.W) == MK_LANE && !c->env.no_fused_compact;  // (k_match_t moves the previous batch's tuples from inside its launch)
+  const bool fuse_ok = !c->env.no_fused_compact;  // (k_match_t and k_match_g move the previous batch's tuples from inside their launches)
   if (sized && fuse_ok && c->nreads > bsz) {  // the second staging set (allocated outside any capture)
     if ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
         (rc = ensure(c, c->tpre_b, c->tpre.cap)))

@@ -4,7 +4,7 @@
 # Per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --steps 5` (kernel
 # statistics + the JSON line of that very run), then separate --pmc passes (never combined with a
 # trace; one counter group per pass; the program directly after `--`) for HBM traffic.  cfg3 also gets
-# the two-kernel path (--index classic) and the second fused kernel (MUSC_MATCH=quad); the SQ
+# the two-kernel path (--index classic) and the second fused kernel (MUSC_MATCH=dma: k_match_g); the SQ
 # instruction mix is profiles/pmc_sq.sh.  Raw output stays under
 # gpurun_out/prof_<tag>/; the summaries land in gpurun_out/<tag>_* -- copy those into profiles/.
 set -o pipefail
@@ -47,7 +47,7 @@ for wl in $wls; do
     done
     mkdir -p $out/pmcs_${wl}_$kind; mv $out/pmc_${wl}_${kind}_[0-9] $out/pmcs_${wl}_$kind/ 2>/dev/null
     key=$wl; [ "$kind" = "classic" ] && key=${wl}_classic
-    python3 profiles/traffic_from_pmc.py $out/pmcs_${wl}_$kind $key k_match_t k_match k_screen_t k_screen k_confirm k_compact_w k_compact > $out/traffic_$key.json
+    python3 profiles/traffic_from_pmc.py $out/pmcs_${wl}_$kind $key k_match_t k_match_g k_screen_t k_screen k_confirm k_compact_w k_compact > $out/traffic_$key.json
     rm -rf $out/pmcs_${wl}_$kind $out/stats_${wl}_$kind/*/*.db 2>/dev/null
   done
 done
@@ -66,11 +66,11 @@ print(json.dumps({k: {kk: round(vv["traffic_bytes_per_launch"] / 1e9, 3) for kk,
 PY
 rm -f gpurun_out/${tag}_traffic.json.parts
 if echo " $wls " | grep -q " cfg3 "; then
-  # k_match (the second fused kernel on the same buckets), kernel statistics only
-  MUSC_MATCH=quad timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_quad -- python3 bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 5 > $out/stats_quad.log 2>&1 || tail -3 $out/stats_quad.log
-  f=$(find $out/stats_quad -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && grep -E "^\"?Name|k_" "$f" > gpurun_out/${tag}_cfg3_quad_kernel_stats.csv
+  # k_match_g (the second fused kernel on the same buckets), kernel statistics only
+  MUSC_MATCH=dma timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_dma -- python3 bench.py --workload cfg3 --no-cpu-baseline --no-survey-scope --steps 5 > $out/stats_dma.log 2>&1 || tail -3 $out/stats_dma.log
+  f=$(find $out/stats_dma -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && grep -E "^\"?Name|k_" "$f" > gpurun_out/${tag}_cfg3_dma_kernel_stats.csv
   # (no copy + kernel time line of the SURVEY-scope leg: rocprofv3 --memory-copy-trace dies at exit on this image, profiles/README.md)
-  rm -rf $out/stats_quad/*/*.db 2>/dev/null
+  rm -rf $out/stats_dma/*/*.db 2>/dev/null
 fi
 du -sh $out

@@ -6,7 +6,7 @@ if [ "$1" != "notest" ]; then
 timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/quick_tests.log 2>&1 || { tail -30 gpurun_out/quick_tests.log; exit 1; }
 tail -1 gpurun_out/quick_tests.log
 fi
-for m in lane quad; do
+for m in lane dma; do
 for wl in cfg3 cfg2; do
   MUSC_MATCH=$m timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-survey-scope --steps 10 > gpurun_out/quick_${wl}_$m.json 2> gpurun_out/quick_${wl}_$m.err || { tail -5 gpurun_out/quick_${wl}_$m.err; exit 1; }
   python - <<PY

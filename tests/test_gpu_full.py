@@ -41,7 +41,7 @@ def _hamming_ok(T_flat, TL, R, h, L, chunk=2_000_000):
     return True
 
 
-@pytest.mark.parametrize("name,index", [("cfg3", "auto"), ("cfg3", "quad"), ("cfg3", "classic"), ("cfg5shard", "auto")])
+@pytest.mark.parametrize("name,index", [("cfg3", "auto"), ("cfg3", "dma"), ("cfg3", "classic"), ("cfg5shard", "auto")])
 def test_baseline_config_at_full_size(name, index, monkeypatch):
     """index "auto": what the library picks -- context buckets + the fused k_match for cfg3 (two
     windows, 100-bp reads: 120 bases of context), line buckets + k_screen_t -> k_confirm
@@ -49,14 +49,14 @@ def test_baseline_config_at_full_size(name, index, monkeypatch):
     "classic" forces the two-kernel path (on 64-byte buckets: a sparse database) for cfg3 as well."""
     import torch
     monkeypatch.delenv("MUSC_MATCH", raising=False)
-    if index == "quad":  # context buckets with k_match instead of k_match_t
-        monkeypatch.setenv("MUSC_MATCH", "quad")
+    if index == "dma":  # context buckets with k_match_g (LDS-DMA, three to four waves per SIMD) instead of k_match_t
+        monkeypatch.setenv("MUSC_MATCH", "dma")
         monkeypatch.delenv("MUSC_INDEX", raising=False)
     elif index == "classic":
         monkeypatch.setenv("MUSC_INDEX", "classic")
     else:
         monkeypatch.delenv("MUSC_INDEX", raising=False)
-    want_kind = 1 if name == "cfg3" and index in ("auto", "quad") else 3 if name == "cfg5shard" else 0  # cfg5: line buckets
+    want_kind = 1 if name == "cfg3" and index in ("auto", "dma") else 3 if name == "cfg5shard" else 0  # cfg5: line buckets
     from muscato_amd import Config, Engine, sorted_hits, synth
     from oracle import literal
     from oracle import muscato_oracle as orc

@@ -19,25 +19,24 @@ from cases import make_case, mutate, rand_seq
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "lane", "quad", "classic", "lines"])
+@pytest.fixture(scope="module", params=["auto", "dma", "classic", "lines"])
 def eng(request):
-    """Every test of this module runs five times: on what the library picks by itself (context
-    buckets wherever the run fits them, matched by k_match_g -- three waves per SIMD, everything from
-    memory by LDS-DMA, kernels_match_dma.hpp -- where the run has two windows, 120-base buckets, records
-    of eight words and no X, and by k_match_t, kernels_match_lane.hpp, elsewhere), with MUSC_MATCH=lane
-    (k_match_t on every context-bucket run), with MUSC_MATCH=quad (k_match: the first fused kernel), with
-    MUSC_INDEX=classic (the two-kernel path k_screen ->
-    k_confirm on the bucket layout the database's density selects: 64-byte buckets for these
-    small databases) and with MUSC_INDEX=lines (the two-kernel path on line buckets, the layout of
-    dense databases such as BASELINE config 5)."""
+    """Every test of this module runs four times: on what the library picks by itself (context
+    buckets wherever the run fits them, matched by k_match_t -- comparisons in the lane that owns the
+    read, kernels_match_lane.hpp), with MUSC_MATCH=dma (k_match_g, kernels_match_dma.hpp: the second
+    fused implementation -- everything from memory by LDS-DMA, three to four waves per SIMD -- where the
+    run has two windows, 120-base buckets, records of eight words and no X; k_match_t elsewhere), with
+    MUSC_INDEX=classic (the two-kernel path k_screen -> k_confirm on the bucket layout the database's
+    density selects: 64-byte buckets for these small databases) and with MUSC_INDEX=lines (the
+    two-kernel path on line buckets, the layout of dense databases such as BASELINE config 5)."""
     from muscato_amd import Engine
     old = {k: os.environ.get(k) for k in ("MUSC_INDEX", "MUSC_MATCH")}
     os.environ.pop("MUSC_INDEX", None)
     os.environ.pop("MUSC_MATCH", None)
     if request.param in ("classic", "lines"):
         os.environ["MUSC_INDEX"] = request.param
-    elif request.param in ("quad", "lane"):
-        os.environ["MUSC_MATCH"] = request.param
+    elif request.param == "dma":
+        os.environ["MUSC_MATCH"] = "dma"
     e = Engine(0)
     e.index_mode = request.param
     yield e
@@ -220,7 +219,7 @@ def test_read_length_strides(eng, maxlen):
     reads = sorted(reads)
     c = orc.Config(Windows=[0, 11], WindowWidth=10, PMatch=0.9, MinDinuc=3, MaxReadLength=maxlen, MMTol=2)
     assert_same(gpu_hits(eng, c, reads, targets, False), as_arr(orc.match_direct(reads, targets, c)))
-    if eng.index_mode in ("auto", "lane"):
+    if eng.index_mode in ("auto", "dma"):
         assert eng.stats()["index_kind"] == (1 if maxlen <= 109 else 2 if maxlen <= 189 else 0)
 
 
@@ -265,7 +264,7 @@ def test_wide_context_buckets_against_literal_oracle(eng, windows, ww, L, pmatch
                                      literal.make_params(c, bloom_size=256_000_000, num_hash=8, nthreads=8))
     got = gpu_hits(eng, c, reads, targets, False)
     st = eng.stats()
-    if eng.index_mode in ("auto", "lane"):
+    if eng.index_mode in ("auto", "dma"):
         assert st["index_kind"] == 2
         if ww <= 12:
             assert st["n_overflow_entries"] > 1000
@@ -885,7 +884,7 @@ def test_reads_with_x_against_an_x_free_database(eng, pmatch, ww, windows, fits)
                                      literal.make_params(c, bloom_size=128_000_000, num_hash=8, nthreads=8))
     got = gpu_hits(eng, c, reads, targets, False)
     st = eng.stats()
-    assert st["index_kind"] == (1 if fits and eng.index_mode in ("auto", "lane") else 3 if eng.index_mode == "lines" else 0)
+    assert st["index_kind"] == (1 if fits and eng.index_mode in ("auto", "dma") else 3 if eng.index_mode == "lines" else 0)
     assert len(got) > 8000
     assert_same(got, exp)
     best = sorted_hits(eng.match(to_cfg(c), apply_mmtol=True))
