@@ -379,7 +379,10 @@ def main() -> int:
         # the compact form when gene | pos | nmiss fit one u32 word: the read index rides as one count
         # byte per read (the list is read-major) -- 5.2 bytes per tuple at cfg4 against 8
         use_compact = sum(pack_bits[1:]) <= 32 and use_packed and not os.environ.get("MUSC_BENCH_NO_COMPACT")
-        cap = HitGatherer.agree_capacity(n0, gdev)
+        # every rank's capacity, agreed ONCE (the sizing pass's counts + 5 %): a pass then posts its transfers without a
+        # collective or a host read (r03 agreed row counts per pass)
+        rank_caps = HitGatherer.agree_caps(n0, gdev)
+        cap = max(rank_caps)
         if use_compact:
             # every rank must be able to use the form (no read with more than 255 tuples, fields fit):
             # tried once on the pass that sized the buffers, agreed over all ranks
@@ -396,9 +399,9 @@ def main() -> int:
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             use_compact = bool(int(okt.item()))
         if use_compact:
-            gatherer = HitGatherer(cap, gdev, compact_reads=max(loaded))
+            gatherer = HitGatherer(cap, gdev, compact_reads=max(loaded), rank_caps=rank_caps)
         else:
-            gatherer = HitGatherer(cap, gdev, packed=use_packed)
+            gatherer = HitGatherer(cap, gdev, packed=use_packed, rank_caps=rank_caps)
         gather_mode = "overlapped (HitGatherer, grouped send/recv), " + (
             "compact tuples: u32 word %s + one count byte per read" % pack_bits[1:] if use_compact else
             "8-byte packed tuples %s" % pack_bits if use_packed else "16-byte tuples")

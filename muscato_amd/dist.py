@@ -58,10 +58,18 @@ class HitGatherer:
     `isend`s its buffer to rank `dst`, `dst` posts one `irecv` per peer into that peer's slab of a
     rank-major receive buffer, all of them inside one ncclGroupStart/End (torch's
     batch_isend_irecv), so the seven incoming transfers of an 8-GPU node run side by side on the
-    seven xGMI links of `dst` instead of one after the other.  Only the rows in use travel: the
-    ranks agree on every rank's row count with one small all_gather per pass (the host knows its own
-    count when the match returns), so link load follows the tuples, not the capacity.  The transfer
-    of pass i runs on the communicator's stream while pass i+1 is being matched.
+    seven xGMI links of `dst` instead of one after the other.  The transfer of pass i runs on the
+    communicator's stream while pass i+1 is being matched.
+
+    NOTHING BLOCKS BETWEEN THE MATCH AND THE TRANSFERS (r04): the size of every rank's transfer is
+    agreed ONCE, when the gatherer is built -- `rank_caps[r]` rows for rank r (agree_caps(): one
+    all_gather of the counts of the sizing pass, + slack) -- so submit() posts its isend / irecv
+    without a collective and without reading a device value on the host (r03 agreed the row counts
+    with an all_gather + .item() per pass: a host synchronisation of all ranks inside a 2 ms
+    step).  Link load follows the tuples as closely as the slack allows: a rank sends its own
+    capacity, not the largest rank's.  The count of a pass rides in the buffer's header row.  A
+    rank whose list does not fit its capacity sends its buffer with the header -1 and raises; `dst`
+    raises when it reads that header (finish / counts): nobody waits in a collective for it.
 
     Every rank owns `depth` send buffers of 1 + `cap` rows; row 0 carries the tuple count.  With
     `packed=True` a row is one int64 word (the layout of musc_hits_copy_packed: half the bytes on
@@ -74,17 +82,22 @@ class HitGatherer:
     concatenation is the global read order."""
 
     def __init__(self, cap: int, device, depth: int = 2, dst: int = 0, group=None, packed: bool = False,
-                 compact_reads: int = 0):
+                 compact_reads: int = 0, rank_caps: Optional[List[int]] = None):
         """compact_reads > 0 selects the compact form (musc_hits_copy_compact; `compact_reads` = the
         largest number of reads any rank holds): a buffer is int32 words [n tuples, n reads] +
         one count byte per read + one word per tuple -- 5 bytes per tuple at one tuple per read,
         against 8 (packed) and 16.  fill(buf) then writes through compact_views(buf) and returns
-        (n, n_reads)."""
+        (n, n_reads).  rank_caps: tuples rank r may send per pass (<= cap; default: cap for every rank)."""
         self.cap, self.depth, self.dst, self.group, self.packed = int(cap), depth, dst, group, packed
         self.compact_reads = int(compact_reads)
         self.cw = (self.compact_reads + 3) // 4  # words of the count bytes
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.rank_caps = [min(int(c), self.cap) for c in rank_caps] if rank_caps is not None else [self.cap] * self.world
+        if len(self.rank_caps) != self.world:
+            raise ValueError("HitGatherer: rank_caps needs one entry per rank")
+        hdr = 2 + self.cw if self.compact_reads else 1
+        self.rows = [hdr + c for c in self.rank_caps]  # rows of rank r's transfer, every pass
         shape, dtype = ((1 + self.cap,), torch.int64) if packed else ((1 + self.cap, 4), torch.int32)
         if self.compact_reads:
             shape, dtype = (2 + self.cw + self.cap,), torch.int32
@@ -113,6 +126,19 @@ class HitGatherer:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         return int(int(t.item()) * slack) + 16
 
+    @staticmethod
+    def agree_caps(n_local: int, device, slack: float = 1.05, group=None) -> List[int]:
+        """Per-rank capacities, agreed ONCE (setup, not per pass): every rank's tuple count of the pass
+        that sized the buffers, plus slack.  max() of the list is the buffer capacity."""
+        world = dist.get_world_size(group)
+        mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+        allr = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine, group=group)
+        else:
+            allr = [mine]
+        return [int(int(t.item()) * slack) + 16 for t in allr]
+
     def _wait(self, k: int) -> None:
         if self.work[k] is not None:
             for w in self.work[k]:
@@ -129,47 +155,42 @@ class HitGatherer:
         nreads = 0
         if self.compact_reads:
             n, nreads = n
-            if nreads > self.compact_reads:
-                raise RuntimeError("HitGatherer: %d reads exceed the agreed capacity %d" % (nreads, self.compact_reads))
         n = int(n)
-        if n > self.cap:
-            raise RuntimeError("HitGatherer: %d hits exceed the agreed capacity %d" % (n, self.cap))
+        mycap = self.rank_caps[self.rank]
+        err = None
+        if self.compact_reads and nreads > self.compact_reads:
+            err = "HitGatherer: %d reads exceed the agreed capacity %d" % (nreads, self.compact_reads)
+        elif n > mycap:
+            err = "HitGatherer: %d hits exceed the agreed capacity %d" % (n, mycap)
+        nh = -1 if err else n  # (the header -1 tells `dst` that this rank gave up; its rows still travel: the sizes are fixed)
         if self.compact_reads:
-            rows = 2 + self.cw + n  # header words, count bytes, one word per tuple
             if self.head is not None:
                 h = self.head[k]  # (free again: the transfers of `depth` passes ago were waited for)
-                h[0] = n
-                h[1] = int(nreads)
+                h[0] = nh
+                h[1] = int(nreads) if not err else 0
                 buf[:2].copy_(h, non_blocking=True)
             else:
-                buf[0] = n
-                buf[1] = int(nreads)
+                buf[0] = nh
+                buf[1] = int(nreads) if not err else 0
         elif self.packed:
-            rows = 1 + n
             if self.head is not None:
-                self.head[k][0] = n
+                self.head[k][0] = nh
                 buf[:1].copy_(self.head[k][:1], non_blocking=True)
             else:
-                buf[0] = n
+                buf[0] = nh
         else:
-            rows = 1 + n
-            if read_base and n:
+            if read_base and n and not err:
                 buf[1:1 + n, 0] += read_base
-            buf[0, 0] = n
-        # every rank's row count, on every rank: the transfers carry the rows in use and nothing else
-        mine = torch.tensor([rows], dtype=torch.int64, device=buf.device)
-        allr = [torch.zeros(1, dtype=torch.int64, device=buf.device) for _ in range(self.world)]
-        if self.world > 1:
-            dist.all_gather(allr, mine, group=self.group)
-            sizes = [int(t.item()) for t in allr]
-        else:
-            sizes = [rows]
+            buf[0, 0] = nh
+        # the transfers: sizes agreed at setup (self.rows) -- no collective, no device value read on the host
         if self.rank == self.dst:
-            ops = [dist.P2POp(dist.irecv, self.recv[k][r][:sizes[r]], r, self.group) for r in range(self.world) if r != self.dst]
+            ops = [dist.P2POp(dist.irecv, self.recv[k][r][:self.rows[r]], r, self.group) for r in range(self.world) if r != self.dst]
         else:
-            ops = [dist.P2POp(dist.isend, buf[:rows], self.dst, self.group)]
+            ops = [dist.P2POp(dist.isend, buf[:self.rows[self.rank]], self.dst, self.group)]
         self.work[k] = dist.batch_isend_irecv(ops) if ops else []
         self.i += 1
+        if err:
+            raise RuntimeError(err)
         return n
 
     def counts(self, k: int) -> List[int]:
@@ -178,7 +199,11 @@ class HitGatherer:
             last = self.recv[k][:, 0]
         else:
             last = self.recv[k][:, 0] if self.packed else self.recv[k][:, 0, 0]
-        return [int(c) for c in last.tolist()]
+        cn = [int(c) for c in last.tolist()]
+        bad = [r for r, c in enumerate(cn) if c < 0]
+        if bad:
+            raise RuntimeError("HitGatherer: rank(s) %s could not fit their tuples into the agreed capacity" % bad)
+        return cn
 
     def compact_views(self, buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """(count bytes [compact_reads] uint8, tuple words [cap] int32) of a compact buffer."""

@@ -113,7 +113,8 @@ def _worker(rank, world, port, seed, outdir, use_gpu, backend="gloo"):
     dev = torch.device("cuda", gpu) if on_dev else torch.device("cpu")
     out = {}
     for packed in (False, True):
-        g = HitGatherer(HitGatherer.agree_capacity(n0, dev), dev, depth=2, packed=packed)
+        caps = HitGatherer.agree_caps(n0, dev)
+        g = HitGatherer(max(caps), dev, depth=2, packed=packed, rank_caps=caps)
         for _ in range(3):  # three passes: buffers are reused from the third on
             n = eng.match_device(cfg, apply_mmtol=True, n_shards=world)
 
@@ -135,7 +136,8 @@ def _worker(rank, world, port, seed, outdir, use_gpu, backend="gloo"):
     # the compact form: one count byte per read + one u32 word per tuple
     nmax = torch.tensor([eng.n_reads], dtype=torch.int64, device=dev)
     dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
-    g = HitGatherer(HitGatherer.agree_capacity(n0, dev), dev, depth=2, compact_reads=int(nmax.item()))
+    caps = HitGatherer.agree_caps(n0, dev)
+    g = HitGatherer(max(caps), dev, depth=2, compact_reads=int(nmax.item()), rank_caps=caps)
     for _ in range(3):
         n = eng.match_device(cfg, apply_mmtol=True, n_shards=world)
 

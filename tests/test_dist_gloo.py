@@ -102,8 +102,11 @@ def _stream_worker(rank, world, port, outdir):
         t[:, 0] = torch.arange(n, dtype=torch.int32)  # shard-local read index
         return t
 
-    cap = HitGatherer.agree_capacity(5 + 3 * rank + 2 * 4, torch.device("cpu"), slack=1.0)
-    g = HitGatherer(cap, torch.device("cpu"), depth=2)
+    # capacities agreed ONCE, per rank (rank 1 holds more tuples than rank 0): no collective per pass afterwards
+    caps = HitGatherer.agree_caps(5 + 3 * rank + 2 * 4, torch.device("cpu"), slack=1.0)
+    assert caps == [5 + 3 * r + 8 + 16 for r in range(world)]
+    cap = max(caps)
+    g = HitGatherer(cap, torch.device("cpu"), depth=2, rank_caps=caps)
     snaps = []
     for p in range(5):
         t = tuples(p)
@@ -120,8 +123,15 @@ def _stream_worker(rank, world, port, outdir):
     if rank == 0:
         snaps.append((cn, g.last_result().clone()))
         torch.save(snaps, os.path.join(outdir, "snaps.pt"))
-    with pytest.raises(RuntimeError):
-        g.submit(lambda buf: cap + 1, 0)
+    # a rank whose list outgrows ITS capacity: it raises, its buffer travels with the header -1 (the sizes are fixed:
+    # nobody is left waiting in a collective), and rank 0 raises when it reads that header
+    if rank == 1:
+        with pytest.raises(RuntimeError):
+            g.submit(lambda buf: caps[1] + 1, 0)
+    else:
+        g.submit(lambda buf: 0, 0)
+        with pytest.raises(RuntimeError, match=r"rank\(s\) \[1\]"):
+            g.finish()
     dist.barrier()
     dist.destroy_process_group()
 
