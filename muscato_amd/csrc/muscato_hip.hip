@@ -1569,6 +1569,8 @@ static void launch_match(musc_ctx* c, uint64_t r0, uint32_t n, int W, int block_
 }
 }  // extern "C++"
 
+static int match_device_impl(musc_ctx* c, const musc_params* P, uint64_t* nhits);
+
 // The geometry-specialised instance a pass may launch: SpecGeom<g> is taken only when EVERY quantity it turns into
 // a constant equals the run's -- window width, window starts, context offset, MinDinuc, the first-window sets, and
 // the TABLE: a direct table of 2 * ww bits (cfg2's 10^8-base database gets a hashed 2^27-bucket table for the same
@@ -1670,7 +1672,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         if (cap.begin(c->stream) != hipSuccess) {  // no capture on this stream: the plain sized pass
           (void)hipGetLastError();
           c->graph_failed = true;
-          return musc_match_device(c, P, nhits);
+          return match_device_impl(c, P, nhits);
         }
       } else {
         HIPCHK(c, hipEventRecord(ev0, c->stream));
@@ -1799,7 +1801,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
         (void)hipGetLastError();
         c->graph_exec = nullptr;
         c->graph_failed = true;
-        return musc_match_device(c, P, nhits);
+        return match_device_impl(c, P, nhits);
       }
       c->graph_epoch = c->data_epoch;
       c->graph_params = *P;
@@ -1819,7 +1821,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
       if (!sized) return fail(c, 12, "internal: a capacity guard fired although every batch was sized (flags %llu)",
                               (unsigned long long)c->h_pinned[3]);
       c->sized_epoch = 0;  // the pass did not fit after all: run it the careful way
-      return musc_match_device(c, P, nhits);
+      return match_device_impl(c, P, nhits);
     }
     if (sized) {
       n_windows = c->h_pinned[8 + 0];
@@ -1837,7 +1839,7 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     c->stats.n_overflow_blocks = check_blocks ? c->h_pinned[5] : ~0ull;
     if (block_mode == 1 && (c->h_pinned[6] || c->stats.n_batches > planned_batches)) {
       c->force_exact_blocks = true;  // screening inconclusive: repeat with exact per-block counters
-      rc = musc_match_device(c, P, nhits);
+      rc = match_device_impl(c, P, nhits);
       c->force_exact_blocks = false;
       return rc;
     }
@@ -1858,8 +1860,18 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
   }
 }
 
+// musc_reads_load_packed32(async = 1) borrows the caller's host buffer "until the next musc_match* returns": that holds
+// on every exit -- a pass that fails early (parameters, no database, an index that cannot be built, a HIP error in a
+// batch) waits for the copies still queued on the upload stream before it returns.  The pieces stay valid on the
+// device, so a later pass packs and matches them.
 int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   if (!c) return 1;
+  const int rc = match_device_impl(c, P, nhits);
+  if (rc != 0 && c->up.active && c->up.s_up) (void)hipStreamSynchronize(c->up.s_up);
+  return rc;
+}
+
+static int match_device_impl(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
   Range rg_pass("musc_match_device");
   int rc = check_params(c, P);
   if (rc) return rc;
@@ -2103,7 +2115,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     if (c->h_pinned[3]) {
       // a guard fired: the pass did not fit after all -- forget the sizing and run it the careful way
       c->sized_epoch = 0;
-      return musc_match_device(c, P, nhits);
+      return match_device_impl(c, P, nhits);
     }
     n_windows = c->h_pinned[8];  // the batch-local block accumulated over the whole pass
     n_cand = c->h_pinned[8 + 3];
@@ -2126,7 +2138,7 @@ int musc_match_device(musc_ctx* c, const musc_params* P, uint64_t* nhits) {
     // screening inconclusive (a hot sketch cell, or more launches than the threshold assumed):
     // repeat the pass with exact per-block counters
     c->force_exact_blocks = true;
-    rc = musc_match_device(c, P, nhits);
+    rc = match_device_impl(c, P, nhits);
     c->force_exact_blocks = false;
     return rc;
   }
