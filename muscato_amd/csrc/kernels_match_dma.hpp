@@ -196,8 +196,9 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
     const uint4* pp[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const uint32_t pl = (uint32_t)i * 8u + (lane >> 3);
-      const uint32_t c = (lane & 7u) ^ (((pl >> 1) & 7u) ^ (pl & 1u));
+      // the chunk: (lane & 7) ^ sw(p) for line p = 8 i + (lane >> 3), sw(p) = ((p >> 1) & 7) ^ (p & 1); (p >> 1) & 7 =
+      // (lane >> 4) | ((i & 1) << 2) and p & 1 = (lane >> 3) & 1: one lane constant, bit 2 flipped on the odd instructions
+      const uint32_t c = ((lane & 7u) ^ (lane >> 4) ^ ((lane >> 3) & 1u)) ^ (((uint32_t)i & 1u) << 2);
       pp[i] = reinterpret_cast<const uint4*>(T + (bq[i] != WB_NONE ? bq[i] : 0u)) + c;
     }
     glds16x8(pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], pp[7], lds_addr(&s_line[wid][0]));

@@ -259,8 +259,9 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     for (int i = 0; i < 8; i++) bq[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((i * 8 + (lane >> 3)) * 4), (int)bbk);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const uint32_t pl = (uint32_t)i * 8u + (lane >> 3);
-      const uint32_t c = (lane & 7u) ^ (((pl >> 1) & 7u) ^ (pl & 1u));
+      // the chunk: (lane & 7) ^ sw(p) for line p = 8 i + (lane >> 3), sw(p) = ((p >> 1) & 7) ^ (p & 1); (p >> 1) & 7 =
+      // (lane >> 4) | ((i & 1) << 2) and p & 1 = (lane >> 3) & 1: one lane constant, bit 2 flipped on the odd loads
+      const uint32_t c = ((lane & 7u) ^ (lane >> 4) ^ ((lane >> 3) & 1u)) ^ (((uint32_t)i & 1u) << 2);
 #ifdef MUSC_LANE_DBG
       if (MUSC_LANE_DBG & 2) continue;
 #endif

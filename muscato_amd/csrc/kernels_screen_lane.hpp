@@ -73,8 +73,8 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
     for (int i = 0; i < 8; i++) bq[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((i * 8 + (lane >> 3)) * 4), (int)lid);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const uint32_t pl = (uint32_t)i * 8u + (lane >> 3);
-      const uint32_t c = (lane & 7u) ^ (((pl >> 1) & 7u) ^ (pl & 1u));
+      // the chunk: (lane & 7) ^ sw(p), p = 8 i + (lane >> 3): one lane constant, bit 2 flipped on the odd loads
+      const uint32_t c = ((lane & 7u) ^ (lane >> 4) ^ ((lane >> 3) & 1u)) ^ (((uint32_t)i & 1u) << 2);
       const u32x4_v* p = reinterpret_cast<const u32x4_v*>(base + (uint64_t)(bq[i] != WB_NONE ? bq[i] : 0u) * 8u) + c;
       const u32x4_v x = __builtin_nontemporal_load(p);
       if (i < 4) a[i] = make_uint4(x.x, x.y, x.z, x.w);

@@ -39,6 +39,7 @@ class Workload:
     revcomp: bool = False  # odd targets are the reverse complements of the even ones (prep_targets -rev)
     total_raw_reads: int = None  # set when the workload fixes the reads over ALL ranks (strong scaling)
     seed_key: str = ""           # what the generator seeds are derived from (the WORKLOADS key)
+    gendat: bool = False         # cmd/muscato_gendat's data instead of the generator above (gendat_like)
 
     @property
     def n_unique_reads(self) -> int:
@@ -58,6 +59,10 @@ WORKLOADS = {
                        0.97, 0, 5),
     "cfg3r150": Workload("cfg3 with 150-bp reads: 25M reads x 1M targets", 1_000_000, 1000, 25_000_000, 150, (0, 20), 15,
                          0.97, 0, 5),
+    # the reference's own scale run (tests/bigtest/test.sh:8-14): muscato_gendat -NumRead=100000 -NumGene=100000, then
+    # -WindowWidth=20 -Windows=10,30,50,70 with PMatch 1, MinDinuc 0, MMTol 0 (the defaults of cmd/muscato/main.go:855-891)
+    "bigtest": Workload("bigtest (tests/bigtest/test.sh): 100k gendat reads x 100k gendat genes", 100_000, 1000, 100_000, 100,
+                        (10, 30, 50, 70), 20, 1.0, 0, 0, gendat=True),
     "tiny": Workload("tiny: 20k reads x 2k targets", 2_000, 1000, 20_000, 100, (0, 20), 15, 0.97, 0, 5),
     # per-GPU shard of cfg5: 200M reads / 8 GPUs against 5M targets + reverse complements (10 Gbp),
     # three windows, MMTol=3 ("exhaustive multi-map")
@@ -98,6 +103,8 @@ def _lut(device):
 def gen_targets(wl: Workload, device, seed: int, copy_frac: float = 0.2, copy_sub: float = 0.02,
                 chunk: int = 100_000) -> torch.Tensor:
     """-> uint8 ASCII tensor [n_targets, target_len] on `device`."""
+    if wl.gendat:  # (reads and genes come from one generator: the first ten reads are planted in the genes)
+        return gendat_like(wl.n_unique_reads, wl.n_targets, wl.read_len, wl.target_len, device, SEED_BASE + 404)[1]
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     T, L = wl.n_targets, wl.target_len
@@ -134,6 +141,8 @@ def gen_unique_reads(wl: Workload, targets_ascii: torch.Tensor, device, seed: in
     (7/9 sampled from targets, 2/9 random), in random order.  With return_plan also the
     bookkeeping of where each read came from: (reads, {"gene", "off": int64 [U], "mm": uint8 [U]})
     -- mm = mismatches of the read against its source placement, 255 for the random reads."""
+    if wl.gendat and not return_plan:
+        return gendat_like(wl.n_unique_reads, wl.n_targets, wl.read_len, wl.target_len, device, SEED_BASE + 404)[0]
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     U = wl.n_unique_reads if n_unique is None else n_unique

@@ -25,7 +25,7 @@ def gendat():
     import torch
     from muscato_amd import synth
     dev = torch.device("cuda", 0)
-    reads, genes = synth.gendat_like(N_READS, N_GENES, READ_LEN, GENE_LEN, dev, synth.SEED_BASE + 404)
+    reads, genes = synth.gendat_like(N_READS, N_GENES, READ_LEN, GENE_LEN, dev, synth.SEED_BASE + 404)  # (bench.py --workload bigtest runs the same generator)
     planted = reads[:10].cpu().numpy()
     R = synth.sort_reads(reads)
     keep = torch.ones(R.shape[0], dtype=torch.bool, device=dev)

@@ -320,6 +320,29 @@ def test_medium_synthetic_against_literal_oracle(eng, xrate):
     assert st["n_reads"] == len(reads)
 
 
+def test_specialised_instance_is_guarded(eng):
+    """BASELINE config 2's shape -- WindowWidth 15, Windows 0,20, MinDinuc 5, 100-base reads, i.e. every quantity the
+    geometry-specialised kernel instance (SpecGeom<1>: BASELINE configs 3 / 4) turns into a constant -- on a database
+    small enough to get a HASHED table, which that instance was not built for (it takes the key for the bucket: the
+    r03 fault, gpurun_out/var.err, was a development build of that kind reading past cfg2's 2^27-bucket table).  The
+    instance is in the library; the host's guard (spec_geom_matches: idx_direct / idx_bits are part of the comparison)
+    must pick the GENERAL instance, and the tuples must equal the CPU port's.  (The whole-cfg3 test asserts the other
+    direction: a direct 2^30-bucket table with the same geometry runs the specialised instance.)"""
+    reads, targets = synthetic_medium(12, 3000, 30000)
+    c = orc.Config(Windows=[0, 20], WindowWidth=15, PMatch=0.97, MinDinuc=5, MaxReadLength=100,
+                   MaxMatches=1000000, MMTol=0)
+    rbuf, roff = literal.concat(reads)
+    gbuf, goff = literal.concat(targets)
+    exp, _, _ = literal.match_arrays(rbuf, roff, gbuf, goff,
+                                     literal.make_params(c, bloom_size=64_000_000, num_hash=8, nthreads=8))
+    got = gpu_hits(eng, c, reads, targets, False)
+    st = eng.stats()
+    # 2 = k_match_t general, 4 = k_match_g general (3 / 5 would be the specialised ones), 0 = two-kernel path
+    assert st["match_variant"] == {"auto": 2, "dma": 4}.get(eng.index_mode, 0), st["match_variant"]
+    assert len(got) > 15000
+    assert_same(got, exp)
+
+
 MEDIUM_MATRIX = [
     # windows, ww, pmatch, mindinuc, mmtol, xrate, n_targets, n_reads
     ((0, 20, 40), 15, 0.97, 3, 3, 0.0, 20000, 200000),      # BASELINE configs[4] shape: odd window count
