@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # same guide: 6.29 TB/s measured float4 copy
-RANDOM_LINES_PER_S = 46.5e9  # measured on this part: random whole 128-byte lines, a quad of lanes per line, nothing else in the kernel (profiles/ub_random_lines.hip)
+RANDOM_LINES_PER_S = 51.5e9  # measured on this part: random whole 128-byte lines, eight lanes per line (the shape the kernels use since r04; the quad shape of r02 / r03 reached 46.5-47.6 G), nothing else in the kernel (profiles/ub_dma_lines.hip, profiles/r04_ub_dma_lines.txt)
 
 
 def line_rate(roof):
@@ -50,7 +50,7 @@ def line_rate(roof):
         roof["lines_per_s_from_traffic"] = lps
         roof["frac_of_measured_random_line_rate"] = lps / RANDOM_LINES_PER_S
     return roof
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 
 
 def measured_traffic(workload_key, kernel):
@@ -128,7 +128,7 @@ def cpu_baseline(wl, cfg, targets_ascii, reads_ascii, eng_factory, n_raw_full, l
         "candsort %.2fs confirm %.2fs (wall %.2fs); %d hits; gpu bit-exact on sample: %s"
         % (s, tp, nthr, t_win, t_bloom, t_scan, t_csort, t_conf, wall, len(exp), exact))
     full, full_src = None, None
-    for cand in ("r03_cpu_full.json", "r02_cpu_full.json"):  # the same port timed on the whole cfg3 workload, once per round, through gpurun (profiles/cpu_full.py)
+    for cand in ("r04_cpu_full.json", "r03_cpu_full.json", "r02_cpu_full.json"):  # the same port timed on the whole cfg3 workload, once per round, through gpurun (profiles/cpu_full.py)
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 full = json.load(f).get(wl.name)

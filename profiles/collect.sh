@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect a round's profile evidence on the GPU box (run from the repo root through gpurun):
-#   profiles/collect.sh r03 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150 (also: cfg3xdb cfg3xreads cfg3xdb_classic cfg3xreads_classic cfg3w3_classic cfg3r150_classic)
+#   profiles/collect.sh r04 [workload ...]        default workloads: cfg3 cfg2 cfg4shard cfg5shard bigtest cfg3w3 cfg3r150 (also: cfg3xdb cfg3xreads cfg3xdb_classic cfg3xreads_classic cfg3w3_classic cfg3r150_classic)
 # Per workload: rocprofv3 --kernel-trace --stats of `bench.py --workload W --steps 5` (kernel
 # statistics + the JSON line of that very run), then separate --pmc passes (never combined with a
 # trace; one counter group per pass; the program directly after `--`) for HBM traffic.  cfg3 also gets
@@ -8,8 +8,8 @@
 # instruction mix is profiles/pmc_sq.sh.  Raw output stays under
 # gpurun_out/prof_<tag>/; the summaries land in gpurun_out/<tag>_* -- copy those into profiles/.
 set -o pipefail
-tag=${1:-r03}; shift
-wls=${@:-cfg3 cfg2 cfg4shard cfg5shard cfg3w3 cfg3r150}
+tag=${1:-r04}; shift
+wls=${@:-cfg3 cfg2 cfg4shard cfg5shard bigtest cfg3w3 cfg3r150}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -37,7 +37,8 @@ for wl in $wls; do
     grep "^{" $out/stats_${wl}_$kind.log > gpurun_out/${tag}_${wl}_${kind}_bench_under_rocprof.json
     i=0
     for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
-               "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; do
+               "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+               "TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
       i=$((i+1))
       if timeout -k 10 400 rocprofv3 --pmc $grp --output-format csv -d $out/pmc_${wl}_${kind}_$i -- $B --steps 1 --warmup 1 > $out/pmc_${wl}_${kind}_$i.log 2>&1; then
         echo "$wl $kind pmc pass $i done: $grp"

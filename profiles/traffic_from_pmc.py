@@ -39,6 +39,10 @@ def main(root, key, prefixes):
             "rdreq_128B": mean.get("TCC_EA0_RDREQ_128B_sum"), "rdreq_bytes": rd,
             "write_size_kb_raw": mean.get("WRITE_SIZE"), "write_bytes": write,
             "tcc_hit": mean.get("TCC_HIT_sum"), "tcc_miss": mean.get("TCC_MISS_sum"),
+            # r04: where the L2's read requests go and how long an L1 miss takes
+            "tcc_req": mean.get("TCC_REQ_sum"), "ea_rdreq": mean.get("TCC_EA0_RDREQ_sum"), "ea_rdreq_dram": mean.get("TCC_EA0_RDREQ_DRAM_sum"),
+            "l2_hit_rate": (mean["TCC_HIT_sum"] / (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"])) if mean.get("TCC_HIT_sum") is not None and mean.get("TCC_MISS_sum") else None,
+            "l1_miss_latency_cycles": (mean["TCP_TCC_READ_REQ_LATENCY_sum"] / mean["TCP_TCC_READ_REQ_sum"]) if mean.get("TCP_TCC_READ_REQ_sum") else None,
             "traffic_bytes_per_launch": fetch + write,
         }
     print(json.dumps({key: out}, indent=1))
