@@ -261,10 +261,16 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
       uint32_t d[NW], nx = 0;
 #pragma unroll
       for (int j = 0; j < NW; j++) {
+        // SPEC: a word no read of this record stride can reach through window k -- below the read's first bit 2 (CL - q1),
+        // or at and beyond 2 (CL - q1) + 2 x 16 (RW - 1) -- is left out AT COMPILE TIME (a test of the run-time mask word
+        // makes every word an exec-masked region of its own: kernels_match_lane.hpp)
+        // (k and j are constants once the window lambda is instantiated and the loop unrolled)
+        const int lo_k = SPEC ? 2 * (S_CL - S_WIN[k >= 0 && k < CTX_MAX_W ? k : 0]) : 0;
+        const bool reached = !SPEC || (32 * (j + 1) > lo_k && 32 * j < lo_k + 32 * (RW - 1));
         const uint32_t x = img[j] ^ c[j];
-        if constexpr (SPEC) d[j] = (x | (x >> 1)) & tb.lm[j];
+        if constexpr (SPEC) d[j] = reached ? (x | (x >> 1)) & tb.lm[j] : 0u;
         else d[j] = base_diff(x, tb.lm[j]);
-        if (!SPEC || tb.lm[j] != 0u) nx = bcnt_add(d[j], nx);
+        if (reached) nx = bcnt_add(d[j], nx);
       }
       uint32_t exact = valid & (z ? ~q1zero : 0xFFFFFFFFu);
 #pragma unroll
@@ -356,14 +362,21 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
       }
       return true;
     };
-    // ... of the lane's own read (in-lane comparisons)
+    // ... of the lane's own read (in-lane comparisons): the first two stay in the lane's registers (k0 / k1: result word,
+    // gene, position) -- nine tenths of the candidates of a wave-tile never see the list, nor phase D its LDS round trips
+    // for them -- a third and later ones go to the list like the overflow entries' (their best joins best_l there)
+    uint32_t kc = 0, k0w = NX_REJECT, k0g = 0, k0p = 0, k1w = NX_REJECT, k1g = 0, k1p = 0;
     auto report_own = [&](uint32_t w, uint32_t gene, uint32_t pos, uint32_t& wck) __attribute__((always_inline)) {
       const bool acc = w != NX_REJECT;
       wck += acc ? 1u : 0u;
-      if (append(acc && !(w & NX_DUP), w, gene, pos)) {
-        const uint32_t v = w & 0xFFFFu;
-        best = v < best ? v : best;
-      }
+      const bool rep = acc && !(w & NX_DUP);
+      const bool first = rep && kc == 0, second = rep && kc == 1, later = rep && kc >= 2;
+      k0w = first ? w : k0w; k0g = first ? gene : k0g; k0p = first ? pos : k0p;
+      k1w = second ? w : k1w; k1g = second ? gene : k1g; k1p = second ? pos : k1p;
+      kc += rep ? 1u : 0u;
+      const uint32_t v = w & 0xFFFFu;
+      best = rep && v < best ? v : best;
+      if (__any(later)) append(later, w, gene, pos);  // (its nmiss is in `best` already: phase D merges the lane's best into best_l)
     };
     const uint32_t rb = lane * 8u + (((lane >> 1) & 7u) ^ (lane & 1u));
     // the part of a window that needs its lines: the header, then the three inline entries, in this lane
@@ -479,7 +492,13 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
       const uint32_t sh = k1 ? shb : sha;
       const int q1 = k1 ? q1b : q1a;
       uint32_t lm[NW];
-      if (ulen != 0xFFFFFFFFu) {
+      if (SPEC && ulen == (uint32_t)S_L) {
+        // (the geometry's masks are constants: no table rows from scalar memory in front of the pass)
+#pragma unroll
+        for (int j = 0; j < NW; j++)
+          lm[j] = k1 ? 0x55555555u & bit_range_mask(2 * (S_CL - S_WIN[1]) - 32 * j, 2 * (S_CL - S_WIN[1]) + 2 * S_L - 32 * j)
+                     : 0x55555555u & bit_range_mask(2 * (S_CL - S_WIN[0]) - 32 * j, 2 * (S_CL - S_WIN[0]) + 2 * S_L - 32 * j);
+      } else if (ulen != 0xFFFFFFFFu) {
         const uint32_t (*rows)[CTXW_WORDS] = mp->lm[__builtin_amdgcn_readfirstlane((int)ulen)];
 #pragma unroll
         for (int j = 0; j < NW; j++) lm[j] = k1 ? rows[1][j] : rows[0][j];
@@ -507,8 +526,14 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
         for (int j = 0; j < NW; j++) {
           d[j] = base_diff((k1 ? ib[j] : ia[j]) ^ c[j], lm[j]);
           nx = bcnt_add(d[j], nx);
-          acc0 = and_or_s(d[j], row10[j], acc0);
-          if (!direct) acc1 |= d[j] & (k1 ? row11[j] : row00[j]);
+          if constexpr (SPEC) {
+            // window 0 of the read in the coordinates of a comparison through window 1: a constant (words it misses fold away)
+            constexpr int sh1c = 2 * (S_CL - S_WIN[1]);
+            acc0 |= d[j] & bit_range_mask(sh1c + 2 * S_WIN[0] - 32 * j, sh1c + 2 * (S_WIN[0] + S_WW) - 32 * j);
+          } else {
+            acc0 = and_or_s(d[j], row10[j], acc0);
+            if (!direct) acc1 |= d[j] & (k1 ? row11[j] : row00[j]);
+          }
         }
         uint32_t exact = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
         if (k1 && acc0) exact &= ~1u;
@@ -600,6 +625,10 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
       PF(9)
     }
     // ===================================================================== phase D: per-read selection, the tuples
+    // best[read] = min nmiss over its reported pairs, tuples with nmiss <= best + MMTol per read
+    // (cmd/muscato_combine_windows/main.go:36-60; all of them when apply_mmtol == 0), a wave scan over the 64 reads,
+    // and the tuples, read-major, into the wave's region of `stage`: a read's own first two from its lane's registers,
+    // then the list's (overflow entries, third and later own candidates)
     {
       const uint32_t nl = nlist;
       const uint32_t nspill = nl > WLIST ? nl - WLIST : 0u;
@@ -616,12 +645,16 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
           else atomicAdd(&block_table[h >> (32 - BLOCK_TABLE_BITS)], cw);
         }
       }
-      {
-        const uint32_t b0 = best_l[lane];
-        best_l[lane] = best < b0 ? best : b0;
-      }
-      cnt_l[lane] = 0;
-      wave_lds_sync();
+      // the read's best: the lane's own (every own candidate, listed or not, went into `best`) joins what the list's
+      // candidates of OTHER lanes (overflow entries) reported for it
+      const uint32_t b0 = total ? best_l[lane] : 0xFFFFFFFFu;  // (only the overflow entries' pass writes it)
+      const uint32_t bestr = best < b0 ? best : b0;
+      const uint32_t thr_own = apply ? bestr + mmtol : 0xFFFFu;
+      const bool s0 = kc > 0 && (k0w & 0xFFFFu) <= thr_own, s1 = kc > 1 && (k1w & 0xFFFFu) <= thr_own;
+      const uint32_t nown = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
+      uint32_t cnum = nown;
+      uint32_t kw = NX_REJECT, kg = 0, kp = 0, ko = 0;
+      const uint32_t nuse = spill_ok ? nl : (nl < WLIST ? nl : WLIST);
       auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) __attribute__((always_inline)) -> uint32_t {
         if (j < WLIST) {
           const uint3 it = list_l[j];
@@ -635,57 +668,68 @@ __global__ __launch_bounds__(TILE, MATCHG_WAVES_OF(SG)) void k_match_g(const uin
         *pos = __hip_atomic_load(sp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
-      const uint32_t nuse = spill_ok ? nl : (nl < WLIST ? nl : WLIST);
-      // the first round of candidates (a lane each; cfg3 has ~53 per wave-tile) stays in registers from the count to
-      // the store: the counting atomic also hands out the tuple's place among its read's; further rounds are walked twice
-      uint32_t kw = NX_REJECT, kg = 0, kp = 0, ko = 0;
-      if (lane < nuse) {
-        const uint32_t w = item(lane, &kg, &kp);
-        const uint32_t rl = w >> 24;
-        const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
-        if ((w & 0xFFFFu) <= thr) {
-          kw = w;
-          ko = atomicAdd(&cnt_l[rl], 1u);
+      if (nuse) {  // (wave-uniform: most wave-tiles of a sparse database have no listed candidate at all)
+        best_l[lane] = bestr;
+        cnt_l[lane] = 0;
+        wave_lds_sync();
+        // the first round of listed candidates (a lane each) stays in registers from the count to the store: the counting
+        // atomic also hands out the tuple's place among its read's listed ones; further rounds are walked twice
+        if (lane < nuse) {
+          const uint32_t w = item(lane, &kg, &kp);
+          const uint32_t rl = w >> 24;
+          const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
+          if ((w & 0xFFFFu) <= thr) {
+            kw = w;
+            ko = atomicAdd(&cnt_l[rl], 1u);
+          }
         }
+        for (uint32_t j = 64 + lane; j < nuse; j += 64) {
+          uint32_t g, p;
+          const uint32_t w = item(j, &g, &p);
+          const uint32_t rl = w >> 24;
+          const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
+          if ((w & 0xFFFFu) <= thr) atomicAdd(&cnt_l[rl], 1u);
+        }
+        wave_lds_sync();
+        cnum += cnt_l[lane];
       }
-      for (uint32_t j = 64 + lane; j < nuse; j += 64) {
-        uint32_t g, p;
-        const uint32_t w = item(j, &g, &p);
-        const uint32_t rl = w >> 24;
-        const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
-        if ((w & 0xFFFFu) <= thr) atomicAdd(&cnt_l[rl], 1u);
-      }
-      wave_lds_sync();
-      const uint32_t cnum = cnt_l[lane];
       const uint32_t inc = wave_scan_incl(cnum);
       const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
-      base_l[lane] = inc - cnum;
+      const uint32_t mybase = inc - cnum;
       const uint64_t base = region0 + used;
       const bool fits = spill_ok && used + tot <= region;
       if (lane == 0) {
         tbase[wt] = (uint32_t)base;
         tcount2[wt] = fits ? tot : 0u;
       }
-      wave_lds_sync();
       if (fits && tot) {
-        if (kw != NX_REJECT) {
-          const uint32_t rl = kw >> 24;
-          stage[base + base_l[rl] + ko] = make_uint4((uint32_t)(r0 + wt * WT + rl), kg, kp, kw & 0xFFFFu);
-        }
-        if (nuse > 64) {
-          for (uint32_t j = 64 + lane; j < nuse; j += 64) {
-            uint32_t g, p;
-            const uint32_t w = item(j, &g, &p);
-            const uint32_t rl = w >> 24, v = w & 0xFFFFu;
-            const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
-            if (v > thr) continue;
-            // places of the later rounds: behind the first round's tuples of the read, counted down from its total
-            const uint32_t ord = atomicAdd(&cnt_l[rl], 0xFFFFFFFFu) - 1u;
-            stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt * WT + rl), g, p, v);
+        const uint32_t rid = (uint32_t)(r0 + wt * WT + lane);
+        if (s0) stage[base + mybase] = make_uint4(rid, k0g, k0p, k0w & 0xFFFFu);
+        if (s1) stage[base + mybase + (s0 ? 1u : 0u)] = make_uint4(rid, k1g, k1p, k1w & 0xFFFFu);
+        if (nuse) {
+          // a listed tuple's place: behind its read's own ones (base_l = where the read's listed tuples start)
+          base_l[lane] = mybase + nown;
+          wave_lds_sync();
+          if (kw != NX_REJECT) {
+            const uint32_t rl = kw >> 24;
+            stage[base + base_l[rl] + ko] = make_uint4((uint32_t)(r0 + wt * WT + rl), kg, kp, kw & 0xFFFFu);
+          }
+          if (nuse > 64) {
+            for (uint32_t j = 64 + lane; j < nuse; j += 64) {
+              uint32_t g, p;
+              const uint32_t w = item(j, &g, &p);
+              const uint32_t rl = w >> 24, v = w & 0xFFFFu;
+              const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
+              if (v > thr) continue;
+              // places of the later rounds: behind the first round's listed tuples of the read, counted down from its total
+              const uint32_t ord = atomicAdd(&cnt_l[rl], 0xFFFFFFFFu) - 1u;
+              stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt * WT + rl), g, p, v);
+            }
           }
         }
       }
       used += tot;
+      nrep += kc < 2u ? kc : 2u;  // (the listed ones below, from one lane)
       nrep += lane == 0 ? nl : 0u;
       PF(10)
     }

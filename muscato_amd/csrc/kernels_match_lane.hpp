@@ -432,8 +432,16 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
 #pragma unroll
       for (int j = 0; j < NW; j++) {
         // (lm has no bit in the high half of the last word, where the context keeps the distance to the target end)
-        d[j] = diff_word(img[j] ^ c[j], xm[j], tm[j], tb.lm[j]);
-        if (!SPEC || tb.lm[j] != 0u) nx = bcnt_add(d[j], nx);  // (SPEC: a word the read does not reach is a constant zero)
+        // SPEC: a word no read of this record stride can reach through window k -- it lies below the read's first bit
+        // 2 (CL - q1), or at and beyond 2 (CL - q1) + 2 x 16 (RW - 1) -- is left out AT COMPILE TIME.  (r03 / early r04
+        // tested the run-time mask word instead: `tb.lm[j] != 0` is a per-lane value once a ragged tile's masks share
+        // the variable, and every word became an exec-masked region of its own -- seven s_and_saveexec / branch /
+        // s_or pairs per entry.)
+        // (k and j are constants once the window lambda is instantiated and the loop unrolled)
+        const int lo_k = SPEC ? 2 * (S_CL - S_WIN[k >= 0 && k < CTX_MAX_W ? k : 0]) : 0;
+        const bool reached = !SPEC || (32 * (j + 1) > lo_k && 32 * j < lo_k + 32 * (RW - 1));
+        d[j] = reached ? diff_word(img[j] ^ c[j], xm[j], tm[j], tb.lm[j]) : 0u;
+        if (reached) nx = bcnt_add(d[j], nx);
       }
       uint32_t exact = valid & (z ? ~q1zero : 0xFFFFFFFFu);
 #pragma unroll

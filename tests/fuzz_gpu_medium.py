@@ -6,7 +6,8 @@ accepted tuples and the best+MMTol selection.  Round 1: seeds 0..85000, no misma
 one MI355X); round 2 (both index kinds, as each configuration selects): seeds 0..56000 with k_match,
 0..80000 with k_match_d where a configuration has at most two windows, and 0..20000 with
 MUSC_FUZZ_READS_X=1 (X in the reads only): no mismatch; round 3 (k_match_t, wide and line buckets): seeds
-0..22000 and 0..9000 with MUSC_FUZZ_READS_X=1, no mismatch, all four index kinds used."""
+0..22000 and 0..9000 with MUSC_FUZZ_READS_X=1, no mismatch, all four index kinds used; round 4: profiles/r04_fuzz_totals.txt (k_match_t with the
+eight-lanes-per-line fetch, and k_match_g with MUSC_MATCH=dma)."""
 import os
 import sys
 import time
@@ -29,6 +30,7 @@ READS_X_ONLY = bool(os.environ.get("MUSC_FUZZ_READS_X"))
 # their windows (at most three per read), so read X meets target X
 DB_X = int(os.environ.get("MUSC_FUZZ_DB_X", "0"))
 KINDS = {0: 0, 1: 0, 2: 0, 3: 0}
+VARIANTS = {0: 0, 2: 0, 3: 0, 4: 0, 5: 0}  # musc_stats.match_variant: 0 two-kernel path, 2 / 3 k_match_t general / specialised, 4 / 5 k_match_g
 
 
 def case(seed):
@@ -105,12 +107,13 @@ def main():
         eb = np.array(sorted(orc.best_filter([tuple(int(x) for x in r) for r in exp], c.MMTol)), dtype=np.uint32).reshape(-1, 4)
         ok = ok and best.shape == eb.shape and bool((best == eb).all()) and e.stats()["n_overflow_blocks"] == 0
         KINDS[e.stats()["index_kind"]] += 1
+        VARIANTS[e.stats()["match_variant"]] = VARIANTS.get(e.stats()["match_variant"], 0) + 1
         if not ok:
             bad += 1
             print("MISMATCH seed", seed, c, len(reads), len(targets), len(got), len(exp), flush=True)
         if seed % 50 == 0:
             print("seed", seed, "hits", len(exp), "elapsed %.0fs" % (time.time() - t0), flush=True)
-    print("fuzz_medium", lo, hi, "bad", bad, "in %.0fs" % (time.time() - t0), "index kinds used", KINDS,
+    print("fuzz_medium", lo, hi, "bad", bad, "in %.0fs" % (time.time() - t0), "index kinds used", KINDS, "kernel variants", VARIANTS,
           "(reads-only X)" if READS_X_ONLY else "(database X, mode %d)" % DB_X if DB_X else "")
 
 
