@@ -481,6 +481,12 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   for (int k = 0; k < W; k++) bb_cur[k] = WB_NONE;
   // prev
   uint32_t wt_prev = 0, nlist_prev = 0, best_prev = 0xFFFFFFFFu, ulen_prev = 0xFFFFFFFFu, total_prev = 0;
+  // A lane's own first OWNK reported candidates stay in its registers (result word, gene, position) from the comparison
+  // to phase D one wave-tile later: nine tenths of a wave-tile's candidates never see the LDS list (r04: report_own
+  // without ballot / mbcnt / ds_write, phase D without list reads and counting atomics for them).  Instances that have no registers to spare (three and four windows, X on either side, wide buckets) keep
+  // every candidate on the list.
+  constexpr int OWNK = (W <= 2 && XM == 0 && !WIDE) ? 2 : 0;
+  uint32_t kc_prev = 0, k0w_prev = NX_REJECT, k0g_prev = 0, k0p_prev = 0, k1w_prev = NX_REJECT, k1g_prev = 0, k1p_prev = 0;
   uint32_t wc_prev[W], bb_prev[W], oc_prev[W], ovf_prev[W];
 #pragma unroll
   for (int k = 0; k < W; k++) wc_prev[k] = oc_prev[k] = ovf_prev[k] = 0, bb_prev[k] = WB_NONE;
@@ -600,7 +606,13 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         const uint32_t sh = k1 ? shb : sha;
         const int q1 = k1 ? q1b : q1a;
         uint32_t lm[NW];
-        if (ul != 0xFFFFFFFFu) {
+        if (SPEC && ul == (uint32_t)S_L) {
+          // (the geometry's masks are constants: no table rows from scalar memory in front of the pass)
+#pragma unroll
+          for (int j = 0; j < NW; j++)
+            lm[j] = k1 ? 0x55555555u & bit_range_mask(2 * (S_CL - S_WIN[W - 1]) - 32 * j, 2 * (S_CL - S_WIN[W - 1]) + 2 * S_L - 32 * j)
+                       : 0x55555555u & bit_range_mask(2 * (S_CL - S_WIN[0]) - 32 * j, 2 * (S_CL - S_WIN[0]) + 2 * S_L - 32 * j);
+        } else if (ul != 0xFFFFFFFFu) {
           const uint32_t (*rows)[CTXW_WORDS] = mp->lm[__builtin_amdgcn_readfirstlane((int)ul)];
 #pragma unroll
           for (int j = 0; j < NW; j++) lm[j] = k1 ? rows[W - 1][j] : rows[0][j];
@@ -609,7 +621,11 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
           for (int j = 0; j < NW; j++) lm[j] = 0x55555555u & bit_range_mask((int)sh - 32 * j, (int)sh + 2 * len - 32 * j);
         }
         uint32_t wm0[NW];  // window 0 of the read, in the coordinates of a comparison through window 1
-        {
+        if constexpr (SPEC) {
+          constexpr int sh1c = 2 * (S_CL - S_WIN[W - 1]);
+#pragma unroll
+          for (int j = 0; j < NW; j++) wm0[j] = bit_range_mask(sh1c + 2 * S_WIN[0] - 32 * j, sh1c + 2 * (S_WIN[0] + S_WW) - 32 * j);
+        } else {
           const uint32_t* __restrict__ row = mp->wm[W - 1][0];
 #pragma unroll
           for (int j = 0; j < NW; j++) wm0[j] = row[j];
@@ -633,7 +649,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
           for (int j = 0; j < NW; j++) {
             d[j] = diff_word((k1 ? ib[j] : ia[j]) ^ c[j], xm[j], tm[j], lm[j]);
             nx = bcnt_add(d[j], nx);
-            acc0 = and_or_s(d[j], wm0[j], acc0);
+            if constexpr (SPEC) acc0 |= d[j] & wm0[j];  // (constants: the words window 0 does not touch fold away)
+            else acc0 = and_or_s(d[j], wm0[j], acc0);
           }
           uint32_t exact = REC_VALID(meta) & (z ? ~q1zero : 0xFFFFFFFFu);
           if (k1 && acc0) exact &= ~1u;
@@ -755,13 +772,14 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
           else atomicAdd(&block_table[h >> (32 - BLOCK_TABLE_BITS)], cw);
         }
       }
-      // the lane's own best joins what the overflow pass found for its read
-      {
-        const uint32_t b0 = best_l[lane];
-        best_l[lane] = best_prev < b0 ? best_prev : b0;
-      }
-      cnt_l[lane] = 0;
-      wave_lds_sync();
+      // the read's best: the lane's own (every own candidate, listed or not, went into best_prev) joins what the
+      // overflow pass reported for it
+      const uint32_t b0 = best_l[lane];
+      const uint32_t bestr = best_prev < b0 ? best_prev : b0;
+      const uint32_t thr_own = apply ? bestr + mmtol : 0xFFFFu;
+      const bool s0 = OWNK >= 1 && kc_prev > 0 && (k0w_prev & 0xFFFFu) <= thr_own, s1 = OWNK >= 2 && kc_prev > 1 && (k1w_prev & 0xFFFFu) <= thr_own;
+      const uint32_t nown = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
+      uint32_t cnum = nown;
       auto item = [&](uint32_t j, uint32_t* gene, uint32_t* pos) __attribute__((always_inline)) -> uint32_t {
         if (j < WLIST) {
           const uint3 it = s_list[pp][wid][j];
@@ -776,68 +794,71 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
         return __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
       const uint32_t nuse = spill_ok ? nl : (nl < WLIST ? nl : WLIST);
-      // The first two rounds of candidates (a lane each: 128 of them, cfg3 has ~53 per wave-tile) stay
-      // in registers from the count to the store: the counting atomic also hands out the tuple's
-      // place among its read's; further rounds (spilled lists) are walked twice.
-      uint32_t kw[2], kg[2], kp[2], ko[2];
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        kw[q] = NX_REJECT;
-        kg[q] = kp[q] = ko[q] = 0;
-        const uint32_t j = (uint32_t)q * 64 + lane;
-        if (j < nuse) {
-          const uint32_t w = item(j, &kg[q], &kp[q]);
+      // The first round of LISTED candidates (a lane each: the overflow entries' and an own third and later one) stays in
+      // registers from the count to the store: the counting atomic also hands out the tuple's place among its read's
+      // listed ones; further rounds (heavy tiles, the instances that list everything) are walked twice.
+      uint32_t kw = NX_REJECT, kg = 0, kp = 0, ko = 0;
+      if (nuse) {  // (wave-uniform)
+        best_l[lane] = bestr;
+        cnt_l[lane] = 0;
+        wave_lds_sync();
+        if (lane < nuse) {
+          const uint32_t w = item(lane, &kg, &kp);
           const uint32_t rl = w >> 24;
           const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
           if ((w & 0xFFFFu) <= thr) {
-            kw[q] = w;
-            ko[q] = atomicAdd(&cnt_l[rl], 1u);
+            kw = w;
+            ko = atomicAdd(&cnt_l[rl], 1u);
           }
         }
+        for (uint32_t j = 64 + lane; j < nuse; j += 64) {
+          uint32_t g, p;
+          const uint32_t w = item(j, &g, &p);
+          const uint32_t rl = w >> 24;
+          const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
+          if ((w & 0xFFFFu) <= thr) atomicAdd(&cnt_l[rl], 1u);
+        }
+        wave_lds_sync();
+        cnum += cnt_l[lane];
       }
-      for (uint32_t j = 128 + lane; j < nuse; j += 64) {
-        uint32_t g, p;
-        const uint32_t w = item(j, &g, &p);
-        const uint32_t rl = w >> 24;
-        const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
-        if ((w & 0xFFFFu) <= thr) atomicAdd(&cnt_l[rl], 1u);
-      }
-      wave_lds_sync();
-      const uint32_t cnum = cnt_l[lane];
       const uint32_t inc = wave_scan_incl(cnum);
       const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
-      base_l[lane] = inc - cnum;
+      const uint32_t mybase = inc - cnum;
       const uint64_t base = region0 + used;
       const bool fits = spill_ok && used + total <= region;
       if (lane == 0) {
         tbase[wt_prev] = (uint32_t)base;
         tcount2[wt_prev] = fits ? total : 0u;
       }
-      wave_lds_sync();
       if (fits && total) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-          if (kw[q] != NX_REJECT) {
-            const uint32_t rl = kw[q] >> 24;
-            stage[base + base_l[rl] + ko[q]] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), kg[q], kp[q], kw[q] & 0xFFFFu);
+        const uint32_t rid = (uint32_t)(r0 + wt_prev * WT + lane);
+        if (s0) stage[base + mybase] = make_uint4(rid, k0g_prev, k0p_prev, k0w_prev & 0xFFFFu);
+        if (s1) stage[base + mybase + (s0 ? 1u : 0u)] = make_uint4(rid, k1g_prev, k1p_prev, k1w_prev & 0xFFFFu);
+        if (nuse) {
+          base_l[lane] = mybase + nown;  // where the read's listed tuples go: behind its own
+          wave_lds_sync();
+          if (kw != NX_REJECT) {
+            const uint32_t rl = kw >> 24;
+            stage[base + base_l[rl] + ko] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), kg, kp, kw & 0xFFFFu);
           }
-        }
-        if (nuse > 128) {
-          for (uint32_t j = 128 + lane; j < nuse; j += 64) {
-            uint32_t g, p;
-            const uint32_t w = item(j, &g, &p);
-            const uint32_t rl = w >> 24, v = w & 0xFFFFu;
-            const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
-            if (v > thr) continue;
-            // places of the later rounds: behind the first two rounds' tuples of the read, counted down from its total
-            const uint32_t ord = atomicAdd(&cnt_l[rl], 0xFFFFFFFFu) - 1u;
-            stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), g, p, v);
+          if (nuse > 64) {
+            for (uint32_t j = 64 + lane; j < nuse; j += 64) {
+              uint32_t g, p;
+              const uint32_t w = item(j, &g, &p);
+              const uint32_t rl = w >> 24, v = w & 0xFFFFu;
+              const uint32_t thr = apply ? best_l[rl] + mmtol : 0xFFFFu;
+              if (v > thr) continue;
+              // places of the later rounds: behind the first round's listed tuples of the read, counted down from its total
+              const uint32_t ord = atomicAdd(&cnt_l[rl], 0xFFFFFFFFu) - 1u;
+              stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), g, p, v);
+            }
           }
         }
       }
       wave_lds_sync();
       best_l[lane] = 0xFFFFFFFFu;  // for the wave-tile after next
       used += total;
+      nrep += kc_prev < (uint32_t)OWNK ? kc_prev : (uint32_t)OWNK;  // (the listed ones from one lane)
       nrep += lane == 0 ? nl : 0u;
     };
     // everything that is left of prev: the pass over its first 64 overflow entries (fetched a window
@@ -854,6 +875,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     uint4 cpv = make_uint4(0, 0, 0, 0);
     uint32_t cpm = 0, cpd = 0;
     uint32_t nlist = 0;           // reported candidates of cur so far (wave-uniform)
+    uint32_t kc = 0, k0w = NX_REJECT, k0g = 0, k0p = 0, k1w = NX_REJECT, k1g = 0, k1p = 0;  // this lane's own first candidates of cur
     uint32_t best = 0xFFFFFFFFu;  // smallest mismatch count reported for this lane's read by the in-lane comparisons
     uint32_t ulen = 0xFFFFFFFFu, total_cur = 0;
     uint32_t wc[W], oc[W], ovf[W];  // accepted pairs of (window, this lane's read); entries beyond the third of this lane's probe of window k, and where in E
@@ -875,19 +897,24 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       ulen = __ballot(active && (uint32_t)rlen != len0) == 0 ? len0 : 0xFFFFFFFFu;
 
       uint3* const list_cur = s_list[par][wid];  // (formed once per wave-tile: its address arithmetic is two multiplies)
-      // a reported candidate of the lane's own read (in-lane comparisons): appended in lane order
+      // a reported candidate of the lane's own read (in-lane comparisons): the first OWNK stay in the lane's registers
+      // (k0 / k1), later ones are appended to the list in lane order
       auto report_own = [&](uint32_t w, uint32_t gene, uint32_t pos, uint32_t& wck) __attribute__((always_inline)) {
         const bool acc = w != NX_REJECT;
         wck += acc ? 1u : 0u;
         const bool rep = acc && !(w & NX_DUP);
-        const unsigned long long vote = __ballot(rep);
+        const bool first = OWNK >= 1 && rep && kc == 0, second = OWNK >= 2 && rep && kc == 1, later = rep && kc >= (uint32_t)OWNK;
+        k0w = first ? w : k0w; k0g = first ? gene : k0g; k0p = first ? pos : k0p;
+        k1w = second ? w : k1w; k1g = second ? gene : k1g; k1p = second ? pos : k1p;
+        kc += rep ? 1u : 0u;
+        const uint32_t v = w & 0xFFFFu;
+        best = rep && v < best ? v : best;
+        const unsigned long long vote = __ballot(later);
         if (vote == 0) return;
         const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
         const uint32_t slot = nlist + below;
         nlist += (uint32_t)__popcll(vote);
-        if (!rep) return;
-        const uint32_t v = w & 0xFFFFu;
-        best = v < best ? v : best;
+        if (!later) return;
         if (slot < WLIST) {
           list_cur[slot] = make_uint3(w, gene, pos);
         } else if (slot - WLIST < sregion) {
@@ -1053,6 +1080,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       wt_prev = wt;
       nlist_prev = nlist;
       best_prev = best;
+      kc_prev = kc; k0w_prev = k0w; k0g_prev = k0g; k0p_prev = k0p; k1w_prev = k1w; k1g_prev = k1g; k1p_prev = k1p;
       ulen_prev = ulen;
       total_prev = total_cur;
 #pragma unroll
