@@ -1,8 +1,10 @@
 #!/bin/bash
 # The committed bench lines of a round (run from the repo root through gpurun):
-#   profiles/bench_lines.sh r04
+#   profiles/bench_lines.sh r04 [a|b]     (two halves: a gpurun call is limited to 20 minutes)
 tag=${1:-r04}
+part=${2:-ab}
 o=gpurun_out
+if [[ $part == *a* ]]; then
 python bench.py --steps 20 --warmup 5 > $o/${tag}_cfg3_bench.json 2> $o/${tag}_cfg3_bench.err || echo "cfg3 FAILED"
 python bench.py --steps 20 --warmup 5 --index classic --no-cpu-baseline --no-survey-scope > $o/${tag}_cfg3_classic_bench.json 2>/dev/null || echo "cfg3 classic FAILED"
 python bench.py --workload cfg2 --steps 50 --warmup 5 > $o/${tag}_cfg2_bench.json 2>/dev/null || echo "cfg2 FAILED"
@@ -13,6 +15,8 @@ python bench.py --workload bigtest --steps 50 --warmup 5 --no-cpu-baseline > $o/
 # the second fused implementation (k_match_g: LDS-DMA, four waves per SIMD) and the general (not geometry-specialised) instances
 MUSC_MATCH=dma python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_cfg3_dma_bench.json 2>/dev/null || echo "cfg3 dma FAILED"
 MUSC_NO_SPEC=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_cfg3_nospec_bench.json 2>/dev/null || echo "cfg3 nospec FAILED"
+fi
+if [[ $part == *b* ]]; then
 # two ranks on ONE GPU over gloo (RCCL refuses two ranks on one device): the N>1 control flow only
 MUSC_BENCH_BACKEND=gloo MUSC_BENCH_DEVICE=0 MUSC_INDEX=classic timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
   --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 1 --reads 5000000 > $o/${tag}_n2_rehearsal.json 2> $o/${tag}_n2_rehearsal.err || { echo "n2 FAILED"; tail -5 $o/${tag}_n2_rehearsal.err; }
@@ -30,6 +34,7 @@ for wl in cfg3w3 cfg3r150; do
   python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_${wl}_bench.json 2>/dev/null || echo "$wl FAILED"
   MUSC_CONTEXT=narrow python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-survey-scope > $o/${tag}_${wl}_classic_bench.json 2>/dev/null || echo "$wl classic FAILED"
 done
+fi
 for f in cfg3 cfg3_dma cfg3_nospec cfg3_classic cfg2 cfg4shard cfg5shard bigtest cfg3w3 cfg3w3_classic cfg3r150 cfg3r150_classic n2_rehearsal; do
   python - <<PY
 import json
