@@ -759,7 +759,7 @@ def main() -> int:
                     "musc_match_device packs and matches each batch as its pieces arrive (a sizing pass: the reads are new to the "
                     "context) -> the tuples " +
                     ("gathered on rank 0 over RCCL every step (HitGatherer: sizes agreed once, no host synchronisation per step), the "
-                     "last step's slabs copied to rank 0's pinned host memory inside the region" if world > 1 else
+                     "last step's slabs copied to rank 0's pinned host memory inside the region" if multi else
                      "into pinned host memory (" + ("compact: u32 word + a count byte per read" if scope["form"] == "compact" else
                                                      "8-byte packed words" if scope["form"] == "packed64" else "16-byte tuples") + ")") +
                     "; database + index resident (uploaded once: one_off).  The pass with everything resident in HBM (r01-r03's `value`) "

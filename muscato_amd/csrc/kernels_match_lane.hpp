@@ -86,6 +86,9 @@ DEV void read_image_n(const Rec<RW>& rec, uint32_t sh, uint32_t (&img)[NW]) {
 }
 
 
+// a tuple on its way out (tried in r04: the non-temporal form of this store -- no difference, profiles/r04_ab_shape_spec_dma.txt)
+DEV void put_tuple(uint4* __restrict__ dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { *dst = make_uint4(a, b, c, d); }
+
 template <int RW, int W, int XM, bool WIDE, int SG>
 __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* __restrict__ rd, uint64_t r0, uint32_t n,
                                                                 const MatchParams* __restrict__ mp,
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     if (!m) return;
     const uint32_t lane = opaque(threadIdx.x) & 63;
     uint4* __restrict__ dst = hits + pbase + d;
-    if (lane < m) dst[lane] = v;
+    if (lane < m) put_tuple(&dst[lane], v.x, v.y, v.z, v.w);
     for (uint32_t i = 64 + lane; i < m; i += 64) dst[i] = pstage[region0 + pused + i];  // a tile with more than 64 tuples
     pused += m;
   };
@@ -832,14 +835,14 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       }
       if (fits && total) {
         const uint32_t rid = (uint32_t)(r0 + wt_prev * WT + lane);
-        if (s0) stage[base + mybase] = make_uint4(rid, k0g_prev, k0p_prev, k0w_prev & 0xFFFFu);
-        if (s1) stage[base + mybase + (s0 ? 1u : 0u)] = make_uint4(rid, k1g_prev, k1p_prev, k1w_prev & 0xFFFFu);
+        if (s0) put_tuple(&stage[base + mybase], rid, k0g_prev, k0p_prev, k0w_prev & 0xFFFFu);
+        if (s1) put_tuple(&stage[base + mybase + (s0 ? 1u : 0u)], rid, k1g_prev, k1p_prev, k1w_prev & 0xFFFFu);
         if (nuse) {
           base_l[lane] = mybase + nown;  // where the read's listed tuples go: behind its own
           wave_lds_sync();
           if (kw != NX_REJECT) {
             const uint32_t rl = kw >> 24;
-            stage[base + base_l[rl] + ko] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), kg, kp, kw & 0xFFFFu);
+            put_tuple(&stage[base + base_l[rl] + ko], (uint32_t)(r0 + wt_prev * WT + rl), kg, kp, kw & 0xFFFFu);
           }
           if (nuse > 64) {
             for (uint32_t j = 64 + lane; j < nuse; j += 64) {
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
               if (v > thr) continue;
               // places of the later rounds: behind the first round's listed tuples of the read, counted down from its total
               const uint32_t ord = atomicAdd(&cnt_l[rl], 0xFFFFFFFFu) - 1u;
-              stage[base + base_l[rl] + ord] = make_uint4((uint32_t)(r0 + wt_prev * WT + rl), g, p, v);
+              put_tuple(&stage[base + base_l[rl] + ord], (uint32_t)(r0 + wt_prev * WT + rl), g, p, v);
             }
           }
         }

@@ -295,6 +295,10 @@ struct musc_ctx {
   DevBuf<uint16_t> nmiss_tab;
   DevBuf<uint32_t> block_table;
   bool force_exact_blocks = false;
+  // the MaxMatches screening of these reads, database and parameters was inconclusive once: later passes over the same
+  // combination start with the exact per-block counters instead of screening, failing and repeating
+  uint64_t exact_epoch = 0;
+  musc_params exact_params;
   int cur_block_mode = 0;          // of the pass in flight
   uint32_t cur_block_thr = 0;
   PathParams last_pp;          // of the last musc_match_device
@@ -1839,6 +1843,8 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     c->stats.n_overflow_blocks = check_blocks ? c->h_pinned[5] : ~0ull;
     if (block_mode == 1 && (c->h_pinned[6] || c->stats.n_batches > planned_batches)) {
       c->force_exact_blocks = true;  // screening inconclusive: repeat with exact per-block counters
+      c->exact_epoch = c->data_epoch;
+      c->exact_params = *P;
       rc = match_device_impl(c, P, nhits);
       c->force_exact_blocks = false;
       return rc;
@@ -1932,7 +1938,8 @@ static int match_device_impl(musc_ctx* c, const musc_params* P, uint64_t* nhits)
   uint64_t max_matches = P->max_matches > 0 ? (uint64_t)P->max_matches : 0x7FFFFFFFull;
   if (P->n_shards > 1) max_matches /= (uint64_t)P->n_shards;  // this context sees one shard of each block
   const uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * MAX_GRID), 0x7FFFFFFFull);
-  int block_mode = P->skip_block_check ? 0 : (c->force_exact_blocks || block_thr < 2 ? 2 : 1);
+  const bool known_exact = c->exact_epoch == c->data_epoch && memcmp(&c->exact_params, P, sizeof *P) == 0;
+  int block_mode = P->skip_block_check ? 0 : (c->force_exact_blocks || known_exact || block_thr < 2 ? 2 : 1);
   const bool check_blocks = block_mode != 0;
   c->cur_block_mode = block_mode;
   c->cur_block_thr = block_thr;
@@ -2138,6 +2145,8 @@ static int match_device_impl(musc_ctx* c, const musc_params* P, uint64_t* nhits)
     // screening inconclusive (a hot sketch cell, or more launches than the threshold assumed):
     // repeat the pass with exact per-block counters
     c->force_exact_blocks = true;
+    c->exact_epoch = c->data_epoch;
+    c->exact_params = *P;
     rc = match_device_impl(c, P, nhits);
     c->force_exact_blocks = false;
     return rc;
