@@ -1097,6 +1097,8 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
     PF(5)
   }
 #ifdef MUSC_LANE_PROF
+  // (the spread of the waves' finishing times: what a static assignment of wave-tiles leaves on the table)
+  if ((gw % 37) == 0 && (threadIdx.x & 63) == 0 && pf_tiles > 4) printf("fin %u %u %llu %llu\n", gw, pf_tiles, pstart, (unsigned long long)__builtin_amdgcn_s_memtime());
   if ((gw == 0 || gw == 1001) && (threadIdx.x & 63) == 0 && pf_tiles > 4)
     printf("wave %u: %u tiles, cycles/tile: total %llu | arrive(wait+lds write) %llu issue %llu hdr %llu phA %llu finish_prev(epass %llu rest+phD %llu) expand %llu img %llu slots %llu end %llu\n", gw, pf_tiles,
            (__builtin_amdgcn_s_memtime() - pstart) / pf_tiles, pf[0] / pf_tiles, pf[1] / pf_tiles, pf[2] / pf_tiles, pf[8] / pf_tiles,

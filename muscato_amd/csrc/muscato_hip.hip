@@ -170,6 +170,7 @@ struct EnvKnobs {
   bool no_fused_compact = false;  // MUSC_NO_FUSED_COMPACT
   bool pipeline = false;      // MUSC_PIPELINE > 0
   bool no_spec = false;       // MUSC_NO_SPEC: never pick a geometry-specialised kernel instance
+  int grid_rounds = 0;        // MUSC_GRID_ROUNDS: the fused kernels' grid = this many times the resident workgroups (0: the default)
   long batch_reads = 0;       // MUSC_BATCH_READS (0: not set)
   void read() {
     *this = EnvKnobs();
@@ -190,6 +191,7 @@ struct EnvKnobs {
     no_fused_compact = getenv("MUSC_NO_FUSED_COMPACT") != nullptr;
     if ((e = getenv("MUSC_PIPELINE"))) pipeline = atoi(e) > 0;
     no_spec = getenv("MUSC_NO_SPEC") != nullptr;
+    if ((e = getenv("MUSC_GRID_ROUNDS"))) grid_rounds = atoi(e);
     if ((e = getenv("MUSC_BATCH_READS"))) batch_reads = atol(e);
   }
 };
@@ -1087,6 +1089,9 @@ static int build_index_ctx(musc_ctx* c, int32_t ww, int32_t CL, int wide) {
 }
 
 // Which of the two fused kernels on context buckets runs
+#ifndef MATCH_GRID_ROUNDS
+#define MATCH_GRID_ROUNDS 1
+#endif
 enum MatchKind { MK_LANE = 2, MK_DMA = 3 };
 // MK_LANE = k_match_t (kernels_match_lane.hpp): every run on context buckets.  MK_DMA = k_match_g
 // (kernels_match_dma.hpp): the same comparisons at three to four waves per SIMD, everything from memory by LDS-DMA --
@@ -1627,10 +1632,17 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
   // the persistent grid = the workgroups that are resident at once (every wave then sees many
   // wave-tiles and the end-of-kernel atomics stay few); the MaxMatches screening threshold is per
   // workgroup-launch, so it follows the grid
-  const unsigned resident = c->rw == 4 ? match_resident<4>(c, pp.W, block_mode)
-                            : c->rw == 8 ? match_resident<8>(c, pp.W, block_mode)
-                            : c->rw == 12 ? match_resident<12>(c, pp.W, block_mode)
-                                          : match_resident<16>(c, pp.W, block_mode);
+  const unsigned resident1 = c->rw == 4 ? match_resident<4>(c, pp.W, block_mode)
+                             : c->rw == 8 ? match_resident<8>(c, pp.W, block_mode)
+                             : c->rw == 12 ? match_resident<12>(c, pp.W, block_mode)
+                                           : match_resident<16>(c, pp.W, block_mode);
+  // MUSC_GRID_ROUNDS (an experiment knob; default 1): a grid of that many times the resident workgroups.  The waves
+  // of a launch do not run at one speed (r04: the slowest wave of a cfg3 launch takes 1.2-1.3 x the mean), which
+  // looks like a tail a dynamically dispatched grid would remove -- it does not: 2 / 4 / 8 / 16 rounds run the cfg3
+  // launch in 1.03 / 1.04 / 1.06 / 1.11 ms against 0.98-0.99 (profiles/r04_ab_shape_spec_dma.txt).  The memory system
+  // is the shared resource: the waves that finish early leave their share to the slow ones, nothing idles.
+  const unsigned rounds = c->env.debug_grid >= 1 ? 1u : (c->env.grid_rounds >= 1 && c->env.grid_rounds <= 64 ? (unsigned)c->env.grid_rounds : (unsigned)MATCH_GRID_ROUNDS);
+  const unsigned resident = resident1 * rounds;
   uint32_t block_thr = (uint32_t)std::min<uint64_t>(max_matches / (planned_batches * resident), 0x7FFFFFFFull);
   if (block_mode == 1 && block_thr < 2) block_mode = 2;
   if (block_mode == 2 && !c->block_table.p) {
