@@ -718,9 +718,9 @@ def main() -> int:
             mv = st.get("match_variant", 2)
             lane = True
             kname = {2: "k_match_t", 3: "k_match_t<geometry 1>", 4: "k_match_g", 5: "k_match_g<geometry 1>"}.get(mv, "k_match_t")
-            fused_note = ("from the second launch of a pass on, a launch also moves the previous batch's staged tuples "
-                          "into the hit list (32 B of traffic per tuple), which `achieved` does not bill"
-                          if lane and st["match_launches"] > 1 else None)
+            fused_note = ("MUSC_FUSED_COMPACT=1: from the second launch of a pass on, a launch also moves the previous batch's staged "
+                          "tuples into the hit list (32 B of traffic per tuple), which `achieved` does not bill"
+                          if os.environ.get("MUSC_FUSED_COMPACT", "0") not in ("", "0") and st["match_launches"] > 1 else None)
             match_roof = {
                 "kernel": kname + " (screen + confirm + per-read selection, context buckets)", "bound": "hbm",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

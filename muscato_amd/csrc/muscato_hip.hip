@@ -167,7 +167,7 @@ struct EnvKnobs {
   int debug_grid = 0;         // MUSC_DEBUG_GRID (0: not set)
   bool debug_sync = false;    // MUSC_DEBUG_SYNC
   int graph = -1;             // MUSC_GRAPH: -1 not set, else its value
-  bool no_fused_compact = false;  // MUSC_NO_FUSED_COMPACT
+  bool fused_compact = false; // MUSC_FUSED_COMPACT=1: the previous batch's tuples move into `hits` from inside the next batch's match launch (r02-r03's default); default: a k_compact_w per batch
   bool pipeline = false;      // MUSC_PIPELINE > 0
   bool no_spec = false;       // MUSC_NO_SPEC: never pick a geometry-specialised kernel instance
   int grid_rounds = 0;        // MUSC_GRID_ROUNDS: the fused kernels' grid = this many times the resident workgroups (0: the default)
@@ -188,7 +188,7 @@ struct EnvKnobs {
     if ((e = getenv("MUSC_DEBUG_GRID"))) debug_grid = atoi(e);
     debug_sync = getenv("MUSC_DEBUG_SYNC") != nullptr;
     if ((e = getenv("MUSC_GRAPH"))) graph = atoi(e);
-    no_fused_compact = getenv("MUSC_NO_FUSED_COMPACT") != nullptr;
+    if ((e = getenv("MUSC_FUSED_COMPACT"))) fused_compact = atoi(e) > 0;
     if ((e = getenv("MUSC_PIPELINE"))) pipeline = atoi(e) > 0;
     no_spec = getenv("MUSC_NO_SPEC") != nullptr;
     if ((e = getenv("MUSC_GRID_ROUNDS"))) grid_rounds = atoi(e);
@@ -1662,7 +1662,12 @@ static int match_ctx_pass(musc_ctx* c, const musc_params* P, const PathParams& p
     (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
   }
-  const bool fuse_ok = !c->env.no_fused_compact;  // (k_match_t and k_match_g move the previous batch's tuples from inside their launches)
+  // Where a batch's staged tuples go to their place in `hits`: a k_compact_w per batch (the default since r04), or
+  // -- MUSC_FUSED_COMPACT=1, r02 / r03's default -- from inside the NEXT batch's match launch.  Measured on cfg3 / the cfg4
+  // shard (profiles/r04_ab_shape_spec_dma.txt): the pass takes the same time either way (3.09-3.24 against 3.25 ms; 1.78
+  // against 1.74), but a launch that also moves 12 M tuples takes 0.96-1.00 ms instead of 0.94-0.95 for work its
+  // algorithmic bytes do not bill: the separate kernel keeps the match kernel's accounting exact.
+  const bool fuse_ok = c->env.fused_compact;
   if (sized && fuse_ok && c->nreads > bsz) {  // the second staging set (allocated outside any capture)
     if ((rc = ensure(c, c->stage_b, c->stage.cap)) || (rc = ensure(c, c->tcount2_b, c->tcount2.cap)) ||
         (rc = ensure(c, c->tpre_b, c->tpre.cap)))

@@ -850,8 +850,15 @@ def test_batches_of_heavy_tiles_move_their_tuples_in_the_next_launch(monkeypatch
         exp_best = sorted_hits(ref.match(to_cfg(ocfg), apply_mmtol=True))
     assert len(exp_all) > 20 * len(reads)
     monkeypatch.delenv("MUSC_INDEX", raising=False)
-    for batch in ("4099", "8192", "7000"):  # 7000: the last batch of 30 000 has a smaller grid
+    # (the in-launch move is opt-in since r04 -- a k_compact_w per batch is the default -- and stays covered here, with
+    # both fused kernels; the plain form runs in every other multi-batch test)
+    for batch, fused, kern in (("4099", "1", ""), ("8192", "1", "dma"), ("7000", "1", ""), ("7000", "1", "dma"), ("4099", "0", "")):  # 7000: the last batch of 30 000 has a smaller grid
         monkeypatch.setenv("MUSC_BATCH_READS", batch)  # read at musc_init
+        monkeypatch.setenv("MUSC_FUSED_COMPACT", fused)
+        if kern:
+            monkeypatch.setenv("MUSC_MATCH", kern)
+        else:
+            monkeypatch.delenv("MUSC_MATCH", raising=False)
         with Engine(0) as eng:
             eng.load_targets(targets)
             eng.load_reads(reads)
@@ -866,6 +873,7 @@ def test_batches_of_heavy_tiles_move_their_tuples_in_the_next_launch(monkeypatch
     # with a candidate list that spills past LDS -- the lists of the wave-tile in hand and of the one
     # before it are alive together and must not share spill space
     monkeypatch.delenv("MUSC_BATCH_READS", raising=False)
+    monkeypatch.delenv("MUSC_MATCH", raising=False)
     monkeypatch.setenv("MUSC_DEBUG_GRID", "3")
     with Engine(0) as eng:
         eng.load_targets(targets)
