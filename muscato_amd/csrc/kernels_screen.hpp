@@ -44,6 +44,16 @@ struct Rec {
       w[4 * q] = a.x; w[4 * q + 1] = a.y; w[4 * q + 2] = a.z; w[4 * q + 3] = a.w;
     }
   }
+  // the same as whole 16-byte pieces the compiler may not split (a plain load it narrows to overlapping dwordx2
+  // pieces, one per (w[i], w[i+1]) pair that ext() shifts: 2 RW - 2 registers for RW words); records stream
+  // through once: non-temporal
+  DEV void load_nt(const uint32_t* __restrict__ p) {
+#pragma unroll
+    for (int q = 0; q < RW / 4; q++) {
+      const u32x4_v a = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(p) + q);
+      w[4 * q] = a.x; w[4 * q + 1] = a.y; w[4 * q + 2] = a.z; w[4 * q + 3] = a.w;
+    }
+  }
   DEV uint32_t len() const { return w[RW - 1] & 0xFFFFu; }
   DEV bool has_x() const { return (w[RW - 1] & READ_HAS_X) != 0; }
   DEV void zero() {
@@ -55,13 +65,18 @@ struct Rec {
   // per-word selects costs 3*RW VALU per call instead).
   DEV uint64_t ext(uint32_t bo) const {
     const uint32_t sh = bo & 31u;
-    uint32_t a = 0, b = 0, c = 0;
+    uint32_t lo = 0, hi = 0;
     switch (__builtin_amdgcn_readfirstlane((int)(bo >> 5))) {
-#define MUSC_EXT_CASE(I)                                             \
-  case I:                                                            \
-    a = w[I < RW ? I : 0];                                           \
-    b = (I + 1 < RW) ? w[I + 1 < RW ? I + 1 : 0] : 0u;               \
-    c = (I + 2 < RW) ? w[I + 2 < RW ? I + 2 : 0] : 0u;               \
+      // (the shifts inside each case, on single registers: with the three words selected first the compiler keeps
+      // every (w[i], w[i+1]) as a 64-bit register pair -- it then loads the record as overlapping dwordx2 pieces,
+      // 2 RW - 2 registers for RW words, and where registers are short spills the pair of the last word)
+#define MUSC_EXT_W(J) ((J) < RW ? w[(J) < RW ? (J) : 0] : 0u)
+#define MUSC_EXT_CASE(I)                                            \
+  case I:                                                           \
+    if (I < RW) {                                                   \
+      lo = __funnelshift_r(MUSC_EXT_W(I), MUSC_EXT_W(I + 1), sh);   \
+      hi = __funnelshift_r(MUSC_EXT_W(I + 1), MUSC_EXT_W(I + 2), sh); \
+    }                                                               \
     break;
       MUSC_EXT_CASE(0) MUSC_EXT_CASE(1) MUSC_EXT_CASE(2) MUSC_EXT_CASE(3)
       MUSC_EXT_CASE(4) MUSC_EXT_CASE(5) MUSC_EXT_CASE(6) MUSC_EXT_CASE(7)
@@ -70,8 +85,27 @@ struct Rec {
 #undef MUSC_EXT_CASE
       default: break;
     }
-    const uint64_t lo = (uint64_t)a | ((uint64_t)b << 32);
-    return sh ? (lo >> sh) | ((uint64_t)c << (64 - sh)) : lo;
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  // 32 bits from bit offset bo (wave-uniform): two words and one v_alignbit -- for the callers that want a window
+  // key of up to 16 bases or a flank (no 64-bit pairs to keep in registers)
+  DEV uint32_t ext32(uint32_t bo) const {
+    const uint32_t sh = bo & 31u;
+    uint32_t r = 0;
+    switch (__builtin_amdgcn_readfirstlane((int)(bo >> 5))) {
+#define MUSC_EXT_CASE(I)                                                                      \
+  case I:                                                                                     \
+    if (I < RW) r = __funnelshift_r(MUSC_EXT_W(I), MUSC_EXT_W(I + 1), sh);                    \
+    break;
+      MUSC_EXT_CASE(0) MUSC_EXT_CASE(1) MUSC_EXT_CASE(2) MUSC_EXT_CASE(3)
+      MUSC_EXT_CASE(4) MUSC_EXT_CASE(5) MUSC_EXT_CASE(6) MUSC_EXT_CASE(7)
+      MUSC_EXT_CASE(8) MUSC_EXT_CASE(9) MUSC_EXT_CASE(10) MUSC_EXT_CASE(11)
+      MUSC_EXT_CASE(12) MUSC_EXT_CASE(13) MUSC_EXT_CASE(14) MUSC_EXT_CASE(15)
+#undef MUSC_EXT_CASE
+#undef MUSC_EXT_W
+      default: break;
+    }
+    return r;
   }
 };
 
@@ -86,13 +120,14 @@ struct Rec<0> {
   DEV uint32_t len() const { return p[rw - 1] & 0xFFFFu; }
   DEV bool has_x() const { return (p[rw - 1] & READ_HAS_X) != 0; }
   DEV uint64_t ext(uint32_t bo) const { return ext64(p, bo); }
+  DEV uint32_t ext32(uint32_t bo) const { return (uint32_t)ext64(p, bo); }
 };
 
 // 8 bases ending just before base `base` of a record, like flank_left on a stream
 template <class R>
 DEV uint32_t rec_flank_left(const R& r, uint32_t base) {
-  if (base >= 8) return (uint32_t)r.ext(2 * (base - 8)) & 0xFFFFu;
-  return (uint32_t)(r.ext(0) << (2 * (8 - base))) & 0xFFFFu;
+  if (base >= 8) return r.ext32(2 * (base - 8)) & 0xFFFFu;
+  return (r.ext32(0) << (2 * (8 - base))) & 0xFFFFu;
 }
 
 // bucket of the read window starting at base q1 (same function as bucket_of on the database)

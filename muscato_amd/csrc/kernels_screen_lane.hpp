@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
   wave_lds_sync();
   const int W = pp.W, ww = pp.ww, min_dinuc = pp.min_dinuc, direct = pp.direct;
   const uint32_t ntiles = (n + TILE - 1) / TILE;
-  uint32_t nvalid = 0, ncand = 0;  // per lane: far below 2^32
+  unsigned long long nvalid = 0, ncand = 0;  // wave-uniform (scalar registers): the wave's totals
   const uint64_t region = desc_cap / gridDim.x;
   const uint64_t region0 = region * blockIdx.x;
   uint64_t used = 0;  // descriptors this wave has needed so far
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
     bool pt = active && rec.len() >= q2;
     if (ww <= 16 && direct) {
       // the usual case: the window key is one 32-bit word, the bucket its bases in reading order
-      const uint32_t key = (uint32_t)rec.ext(2 * q1) & (ww == 16 ? 0xFFFFFFFFu : ((1u << (2 * ww)) - 1u));
+      const uint32_t key = rec.ext32(2 * q1) & (ww == 16 ? 0xFFFFFFFFu : ((1u << (2 * ww)) - 1u));
       if (min_dinuc > 0) pt = pt && key_dinucs16(key, ww) >= min_dinuc;
       return pt ? __brev(key) >> (32 - 2 * ww) : WB_NONE;
     }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
     return pt ? rec_bucket(rec, rec, false, q1, ww, pp.bits, direct) : WB_NONE;
   };
   auto rec_at = [&](uint32_t i, Rec<RW>& rec) __attribute__((always_inline)) {
-    rec.load(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW, RW);
+    rec.load_nt(rd + (r0 + (i < n ? i : 0)) * (uint64_t)RW);
   };
 
 #ifdef SCRT_PROF
@@ -176,11 +176,12 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
           issue64(TL, b_nx, va, vb);
         }
         const bool pv = b_cur != WB_NONE;
-        const uint32_t rfl = pv ? (rec_flank_left(rec, (uint32_t)q1) | (((uint32_t)rec.ext(2u * q2) & 0xFFFFu) << 16)) : 0u;
+        const uint32_t rfl = pv ? (rec_flank_left(rec, (uint32_t)q1) | ((rec.ext32(2u * q2) & 0xFFFFu) << 16)) : 0u;
         s_rfl[lane] = rfl;
         s_lenbud[lane] = lenbud;
         if (active) wb[(uint64_t)i * W + k] = b_cur;
         valid |= pv ? 1u << k : 0u;
+        nvalid += (uint32_t)__popcll(__ballot(pv));
         SPF(2)
         wave_lds_sync();
         // ---- lane p takes line p: its header first -- the lines of eight that hold the entries beyond the
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
         // like the next step's lines, while the seven inline entries are tested
         const uint4 h = s_line[rb];
         const uint32_t cnt = pv ? h.x : 0u;
-        ncand += cnt;
+        ncand += (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(cnt < 0xFFFFFFu ? cnt : 0xFFFFFFu), 63);
 #if defined(SCRT_DBG) && (SCRT_DBG & 2)
         const uint32_t nl = 0;
 #else
@@ -272,7 +273,6 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
 #endif
         b_cur = b_nx;
       }
-      nvalid += __popc(valid);
       if (active) rvalid[i] = valid;
       rec = rec_nx;
     }
@@ -290,11 +290,7 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
            pf[3] / pf_steps, pf[4] / pf_steps, pf[5] / pf_steps, pf[6] / pf_steps);
 #endif
   // (a wave is a workgroup here: one reduction per wave and a handful of atomics from its first lane)
-  unsigned long long v0 = nvalid, v1 = ncand;
-  for (int d = 32; d; d >>= 1) {
-    v0 += __shfl_xor(v0, d);
-    v1 += __shfl_xor(v1, d);
-  }
+  const unsigned long long v0 = nvalid, v1 = ncand;
   if (lane == 0) {
     if (v0) atomicAdd(&counters[0], v0);
     if (v1) atomicAdd(&counters[3], v1);
