@@ -218,7 +218,9 @@ DEV int rec_count_dinuc(const R& r, const R& m, bool has_m, uint32_t q1, int ww)
 #define SCR_OWN 2048  // overflow items per chunk whose owner is looked up directly
 #define SCR_PROBES (2 * TILE)  // probes per chunk: two windows of every read of the tile
 
-// fit rules + flank filter for one index entry against one probe; true = worth a target gather
+// fit rules + flank filter for one index entry against one probe; true = worth a target gather.  Written without
+// short-circuit evaluation on purpose: every term is a vector compare into a scalar mask and the masks are combined
+// by the scalar unit -- with && / if-else the compiler wraps each entry's test in nested exec-mask regions.
 DEV bool screen_entry_ok(const uint4 ent, int q1, int ww, uint32_t rfl, uint32_t lenbud, uint32_t* zflag) {
   const int q2 = q1 + ww;
   const int rlen = (int)(lenbud & 0xFFFFu);
@@ -230,13 +232,12 @@ DEV bool screen_entry_ok(const uint4 ent, int q1, int ww, uint32_t rfl, uint32_t
   const int tcap = left + right;  // target length, saturated (exact below 65535)
   if (lim0 > tcap) lim0 = tcap;
   const bool fit0 = rlen <= lim0;
-  bool ok = q1 <= left;                  // p = jx - q1 >= 0
-  if (left == 0) ok = ok && fit0;        // window at target position 0: pos-0 path
-  else ok = ok && (rlen - q1 <= right);  // p + len <= T
+  // p = jx - q1 >= 0; a window at target position 0 takes the pos-0 path, any other needs p + len <= T
+  const bool fits = (left == 0) ? fit0 : (rlen - q1 <= right);
   const uint32_t x = rfl ^ ent.w;
   const uint32_t d = (x | (x >> 1)) & 0x55555555u & fmask;
-  ok = ok && ((uint32_t)__popc(d) <= (lenbud >> 16));
-  *zflag = (left == q1 && !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
+  const bool ok = (q1 <= left) & fits & ((uint32_t)__popc(d) <= (lenbud >> 16));
+  *zflag = ((left == q1) & !fit0) ? 1u : 0u;  // p == 0 but the pos-0 path rejects
   return ok;
 }
 

@@ -51,6 +51,11 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
   for (uint32_t t = threadIdx.x; t < CONF_NM; t += 64) s_nm[t] = t <= (uint32_t)pp.max_len ? nmiss_tab[t] : (uint16_t)0;
   wave_lds_sync();
   const int W = pp.W, ww = pp.ww, min_dinuc = pp.min_dinuc, direct = pp.direct;
+  // the window starts and the position width, once: read where they are used they are scalar loads inside the step
+  // and inside the survivors' loop, each with its own wait (a spilled scalar register comes back by v_readlane)
+  const bool wide = pp.wide != 0;
+  const int win0 = pp.win[0], win1 = pp.win[1], win2 = pp.win[2], win3 = pp.win[3];
+  auto win_of = [&](int k) __attribute__((always_inline)) -> int { return k == 0 ? win0 : k == 1 ? win1 : k == 2 ? win2 : k == 3 ? win3 : pp.win[k]; };
   const uint32_t ntiles = (n + TILE - 1) / TILE;
   unsigned long long nvalid = 0, ncand = 0;  // wave-uniform (scalar registers): the wave's totals
   const uint64_t region = desc_cap / gridDim.x;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
   // the bucket of a read's window k (cmd/muscato_window_reads/main.go:106-118 ==
   // cmd/muscato_screen/main.go:174-185: long enough, CountDinuc >= MinDinuc), WB_NONE when it takes no part
   auto bucket_k = [&](const Rec<RW>& rec, bool active, int k) __attribute__((always_inline)) -> uint32_t {
-    const uint32_t q1 = (uint32_t)pp.win[k], q2 = q1 + (uint32_t)ww;
+    const uint32_t q1 = (uint32_t)win_of(k), q2 = q1 + (uint32_t)ww;
     bool pt = active && rec.len() >= q2;
     if (ww <= 16 && direct) {
       // the usual case: the window key is one 32-bit word, the bucket its bases in reading order
@@ -132,10 +137,10 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
           const uint32_t left = ent.z & 0xFFFFu;
           const uint32_t pos_ok = left < 65535u ? 1u : 0u;
           // global offset of the placement (40 bits in wide mode: the high byte rides in x)
-          const uint64_t gp = (((uint64_t)(pp.wide ? ent.x >> 24 : 0u) << 32) | ent.y) - (uint64_t)q1;
+          const uint64_t gp = (((uint64_t)(wide ? ent.x >> 24 : 0u) << 32) | ent.y) - (uint64_t)q1;
           desc[base + slot] = make_uint4((tile * TILE + rit) | ((uint32_t)(gp >> 32) << 24), (uint32_t)gp,
                                          (uint32_t)k | (((zm >> e) & 1u) << 4) | (pos_ok << 5) | ((left - (uint32_t)q1) << 6),
-                                         pp.wide ? (ent.x & 0xFFFFFFu) : ent.x);
+                                         wide ? (ent.x & 0xFFFFFFu) : ent.x);
         }
         slot++;
       }
@@ -161,20 +166,25 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
       if (sub + 1 < TILE / 64) rec_at(i + 64, rec_nx);
 #pragma unroll 1
       for (int k = 0; k < W; k++) {
-        const int q1 = pp.win[k];
+        const int q1 = win_of(k);
         const uint32_t q2 = (uint32_t)q1 + (uint32_t)ww;
         SPF(0)
         // ---- the step's 64 lines arrive; the next step's are requested at once
         land64(va, vb);
         SPF(1)
         uint32_t b_nx = WB_NONE;
-        if (k + 1 < W) {
-          b_nx = bucket_k(rec, active, k + 1);
-          issue64(TL, b_nx, va, vb);
-        } else if (sub + 1 < TILE / 64) {
-          b_nx = bucket_k(rec_nx, i + 64 < n, 0);
-          issue64(TL, b_nx, va, vb);
-        }
+        auto issue_next = [&]() __attribute__((always_inline)) {
+          if (k + 1 < W) {
+            b_nx = bucket_k(rec, active, k + 1);
+            issue64(TL, b_nx, va, vb);
+          } else if (sub + 1 < TILE / 64) {
+            b_nx = bucket_k(rec_nx, i + 64 < n, 0);
+            issue64(TL, b_nx, va, vb);
+          }
+        };
+#ifndef SCRT_OVF_FIRST
+        issue_next();
+#endif
         const bool pv = b_cur != WB_NONE;
         const uint32_t rfl = pv ? (rec_flank_left(rec, (uint32_t)q1) | ((rec.ext32(2u * q2) & 0xFFFFu) << 16)) : 0u;
         s_rfl[lane] = rfl;
@@ -215,20 +225,23 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
           list_lines(0);
           issue64(E, lane < (total < 64u ? total : 64u) ? s_oln[lane] : WB_NONE, oa, ob);
         }
+#ifdef SCRT_OVF_FIRST
+        issue_next();
+#endif
         SPF(3)
         {
           uint32_t okm = 0, zm = 0;
 #pragma unroll
+          // (straight-line: the seven entries are read from the lane's own line whether they exist or not, and every
+          // test is evaluated -- no exec-mask regions, the LDS reads of all seven issued ahead of the first test; four
+          // probes in five have more than seven entries, so almost nothing was skipped by testing `live` first)
           for (int s = 0; s < LINE_INLINE; s++) {
-            const bool live = (uint32_t)s < cnt;
-            if (!__any(live)) break;
             const uint4 ent = s_line[rb ^ (uint32_t)(s + 1)];
             uint32_t z = 0;
-            bool ok = live;
+            bool ok = screen_entry_ok(ent, q1, ww, rfl, lenbud, &z) & ((uint32_t)s < cnt);
 #if defined(SCRT_DBG) && (SCRT_DBG & 1)
             ok = false;
 #endif
-            if (ok) ok = screen_entry_ok(ent, q1, ww, rfl, lenbud, &z);
             okm |= ok ? 1u << s : 0u;
             zm |= (ok ? z : 0u) << s;
           }
@@ -252,15 +265,12 @@ __global__ __launch_bounds__(64, SCRT_WAVES) void k_screen_t(const uint32_t* __r
           uint32_t okm = 0, zm = 0;
 #pragma unroll
           for (int s = 0; s < 8; s++) {
-            const bool live = (uint32_t)s < ocn;
-            if (!__any(live)) break;
             const uint4 ent = s_line[rb ^ (uint32_t)s];
             uint32_t z = 0;
-            bool ok = live;
+            bool ok = screen_entry_ok(ent, q1, ww, orfl, olb, &z) & ((uint32_t)s < ocn);
 #if defined(SCRT_DBG) && (SCRT_DBG & 1)
             ok = false;
 #endif
-            if (ok) ok = screen_entry_ok(ent, q1, ww, orfl, olb, &z);
             okm |= ok ? 1u << s : 0u;
             zm |= (ok ? z : 0u) << s;
           }
