@@ -6,12 +6,13 @@ best filter) on MI355X, with the kernels' HBM rooflines and a CPU baseline.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over this rank's unique reads, which are already resident
-in HBM, against the resident target database + k-mer index; hits stay on the device (N=1) or
-are concatenated on rank 0 over RCCL (N>1, inside the timed region).  `value` is that
-steady-state figure (`config.timed_region` says so); beside it the line carries
-  * `survey_scope`  SURVEY.md 8d's timer: packed reads in pinned host memory -> upload -> match
-                    -> tuples in pinned host memory (PCIe both ways; never `value`),
+A "step" (`value`, `ms_per_step`; since r04) is one pass on SURVEY.md 8d's timer scope: this rank's packed
+unique reads in pinned host memory -> asynchronous upload -> pack + match against the resident target
+database + k-mer index -> the tuples in pinned host memory (N>1: every rank's tuples to its own pinned host
+memory AND concatenated on rank 0 over RCCL, inside the timed region).  Beside it the line carries
+  * `kernel_pipeline` the pass with reads, database and index resident in HBM and the hits left there (N>1:
+                    gathered on rank 0): r01-r03's `value`; `roofline` and `per_step` describe this pass,
+  * `survey_scope`  the parts of the step (serial run, what the overlap hides, bytes both ways),
   * `graph_replay`  the sized pass replayed as one hipGraph launch (MUSC_GRAPH=1, opt-in),
   * `first_pass_ms` one pass over freshly loaded reads (the sizing pass the CLI always takes),
     `cold_pass_ms`  the first pass of the process (buffer allocation included),
@@ -513,6 +514,18 @@ def main() -> int:
             elif n:
                 eng.hits_to(h_hits.data_ptr(), n, False)
 
+        h_own = [None]
+
+        def own_to_host():
+            # several GPUs: every rank's tuples of the step reach pinned host memory too, as at N = 1 -- the buffer the
+            # rank has just handed to the gather (header + count bytes + words, or packed words) copied over the rank's
+            # own PCIe link while RCCL reads the same buffer; without this a step at N > 1 would do less than one at N = 1
+            k_ = (gatherer.i - 1) % gatherer.depth
+            src = gatherer.send[k_][:gatherer.rows[rank]]
+            if h_own[0] is None:
+                h_own[0] = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            h_own[0].copy_(src)
+
         def scope_step(async_upload=True):
             t1 = time.perf_counter()
             eng.load_reads_packed32_ptr(h_packed.data_ptr(), 0, 0, wl.read_len, n_loaded, async_upload=async_upload)
@@ -522,6 +535,7 @@ def main() -> int:
             overflow_seen[0] = max(overflow_seen[0], eng.stats()["n_overflow_blocks"])
             if gatherer is not None:
                 gatherer.submit(lambda buf: fill_gather(buf, n), read_base)
+                own_to_host()
             else:
                 download(n)
                 gathered_n[0] = n
@@ -758,8 +772,10 @@ def main() -> int:
                     "each rank's packed unique reads (2 bits per base) in pinned host memory -> asynchronous upload in pieces -> "
                     "musc_match_device packs and matches each batch as its pieces arrive (a sizing pass: the reads are new to the "
                     "context) -> the tuples " +
-                    ("gathered on rank 0 over RCCL every step (HitGatherer: sizes agreed once, no host synchronisation per step), the "
-                     "last step's slabs copied to rank 0's pinned host memory inside the region" if multi else
+                    ("into the rank's pinned host memory every step (its gather buffer, copied over its own PCIe link, as at N = 1) AND "
+                     "gathered on rank 0 over RCCL every step (HitGatherer: sizes agreed once, no host synchronisation per step; the "
+                     "transfers of step i run while step i+1 uploads and matches), the last step's concatenated slabs copied to rank "
+                     "0's pinned host memory inside the region" if multi else
                      "into pinned host memory (" + ("compact: u32 word + a count byte per read" if scope["form"] == "compact" else
                                                      "8-byte packed words" if scope["form"] == "packed64" else "16-byte tuples") + ")") +
                     "; database + index resident (uploaded once: one_off).  The pass with everything resident in HBM (r01-r03's `value`) "
