@@ -53,7 +53,7 @@ def main():
         json.dump(traffic, open(os.path.join(P, tag + "_traffic.json"), "w"), indent=1)
         n += 1
     for src, dst in (("pmc_sq_t.txt", "_cfg3_sq_t.txt"), ("pmc_mem_t.txt", "_cfg3_pmc_mem_t.txt"), ("pmc_sq_s5.txt", "_cfg5_sq_k_screen_t.txt"),
-                     (tag + "_fuzz_totals.txt", "_fuzz_totals.txt"), (tag + "_ub_span_gather.txt", "_ub_span_gather.txt")):
+                     (tag + "_fuzz_totals.txt", "_fuzz_totals.txt")):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, tag + dst))
             n += 1
