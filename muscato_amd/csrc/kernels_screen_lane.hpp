@@ -8,9 +8,10 @@
 // wave's memory round trip and four workgroups per CU cannot hide twenty of those per tile.  Neither
 // fewer lines per probe (line buckets: 1.75 instead of 3) nor more loads in flight per lane moved
 // it.  Here a WAVE works alone on its 64 reads of the tile (k_match_t's way, kernels_match_lane.hpp):
-//   * a probe's line -- 16-byte header + seven entries -- is fetched by a quad of lanes (32 bytes per
-//     lane, coalesced), written to a per-wave line buffer in LDS and read back whole by the lane that
-//     owns the read (the buffer is XOR-swizzled: no bank conflicts either way); that lane tests the
+//   * a probe's line -- 16-byte header + seven entries -- is fetched by EIGHT lanes (16 contiguous bytes per
+//     lane: a load instruction brings eight whole lines; r03 used a quad and two loads per line), written to a
+//     per-wave line buffer in LDS and read back whole by the lane that owns the read (the buffer is
+//     XOR-swizzled and the swizzle is applied to the SOURCE chunk: no bank conflicts either way); that lane tests the
 //     seven entries against its own read's flanks and length (screen_entry_ok: the fit rules of
 //     cmd/muscato_screen/main.go:294-316, 335-363 + cmd/muscato_confirm/main.go:201-203 and the 8+8
 //     flank pre-filter) straight from registers;
