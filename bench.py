@@ -514,17 +514,49 @@ def main() -> int:
             elif n:
                 eng.hits_to(h_hits.data_ptr(), n, False)
 
-        h_own = [None]
+        # Several GPUs: SURVEY.md 8d stops the clock at "result tuples for all shards on rank 0's host".  Rank 0 owns ONE
+        # pinned host buffer with a slab per rank (a file in /dev/shm that every rank maps and registers with the HIP
+        # runtime); every step each rank copies the buffer it has just handed to the gather -- header + count bytes +
+        # words, or packed words -- into its slab over ITS OWN PCIe link, while RCCL concatenates the same buffers in rank
+        # 0's HBM.  (Rank 0 pulling all ranks' tuples out of its HBM instead would put 8 shards' bytes per step on one link.)
+        h_all = [None, None, None]  # the mapping (kept alive), this rank's slab, the file's path
+
+        def open_host_slabs():
+            import mmap
+            import numpy as np
+            esz = gatherer.send[0].element_size() * (4 if gatherer.send[0].dim() == 2 else 1)
+            sizes = [((r_ * esz + 4095) // 4096) * 4096 for r_ in gatherer.rows]  # page-aligned slabs
+            path = [None]
+            if rank == 0:
+                path[0] = "/dev/shm/musc_bench_%d_%s" % (os.getpid(), os.environ.get("MASTER_PORT", "0"))
+                with open(path[0], "wb") as f:
+                    f.truncate(sum(sizes))
+            dist.broadcast_object_list(path, src=0)
+            with open(path[0], "r+b") as f:
+                mm = mmap.mmap(f.fileno(), sum(sizes))
+            arr = np.frombuffer(mm, dtype=np.uint8)
+            whole = torch.from_numpy(arr)
+            pinned = False
+            if gatherer.send[0].is_cuda:
+                try:
+                    pinned = int(torch.cuda.cudart().cudaHostRegister(whole.data_ptr(), whole.numel(), 0)) == 0
+                except Exception as e:  # pageable then: slower, still correct
+                    log("host slabs not registered (%r): pageable copies" % (e,))
+            off = sum(sizes[:rank])
+            mine = whole[off:off + gatherer.rows[rank] * esz].view(gatherer.send[0].dtype)
+            if gatherer.send[0].dim() == 2:
+                mine = mine.view(-1, 4)
+            h_all[0], h_all[1], h_all[2] = (mm, arr, whole, pinned), mine, path[0]
+            dist.barrier()
+            if rank == 0:
+                os.unlink(path[0])  # (every rank holds its mapping; the name is no longer needed)
 
         def own_to_host():
-            # several GPUs: every rank's tuples of the step reach pinned host memory too, as at N = 1 -- the buffer the
-            # rank has just handed to the gather (header + count bytes + words, or packed words) copied over the rank's
-            # own PCIe link while RCCL reads the same buffer; without this a step at N > 1 would do less than one at N = 1
             k_ = (gatherer.i - 1) % gatherer.depth
-            src = gatherer.send[k_][:gatherer.rows[rank]]
-            if h_own[0] is None:
-                h_own[0] = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
-            h_own[0].copy_(src)
+            h_all[1].copy_(gatherer.send[k_][:gatherer.rows[rank]])
+
+        if gatherer is not None:
+            open_host_slabs()
 
         def scope_step(async_upload=True):
             t1 = time.perf_counter()
@@ -574,7 +606,9 @@ def main() -> int:
                  "host_ms_queue_upload": scope_t["queue_upload"] * 1e3 / args.steps, "host_ms_match_call": scope_t["match"] * 1e3 / args.steps,
                  "host_ms_tuples_out": scope_t["down"] * 1e3 / args.steps,
                  "bytes_up": int(h_packed.numel()),
-                 "bytes_down": int(n0 * 4 + n_loaded) if form == "compact" else int(n0 * 8) if form == "packed64" else int(n0 * 16)}
+                 "bytes_down": (int(h_all[1].numel() * h_all[1].element_size()) if h_all[1] is not None else
+                                int(n0 * 4 + n_loaded) if form == "compact" else int(n0 * 8) if form == "packed64" else int(n0 * 16)),
+                 "host_slabs_pinned": (bool(h_all[0][3]) if h_all[0] is not None else None)}
         match()  # (the legs below start from a sized pass again)
 
     legs = {}
@@ -772,10 +806,11 @@ def main() -> int:
                     "each rank's packed unique reads (2 bits per base) in pinned host memory -> asynchronous upload in pieces -> "
                     "musc_match_device packs and matches each batch as its pieces arrive (a sizing pass: the reads are new to the "
                     "context) -> the tuples " +
-                    ("into the rank's pinned host memory every step (its gather buffer, copied over its own PCIe link, as at N = 1) AND "
-                     "gathered on rank 0 over RCCL every step (HitGatherer: sizes agreed once, no host synchronisation per step; the "
-                     "transfers of step i run while step i+1 uploads and matches), the last step's concatenated slabs copied to rank "
-                     "0's pinned host memory inside the region" if multi else
+                    ("into rank 0's host memory every step -- ONE pinned buffer owned by rank 0 with a slab per rank (shared memory, "
+                     "registered with the HIP runtime by every rank), each rank copying its gather buffer into its slab over its own "
+                     "PCIe link -- AND concatenated in rank 0's HBM over RCCL every step (HitGatherer: sizes agreed once, no host "
+                     "synchronisation per step; the transfers of step i run while step i+1 uploads and matches), the last step's "
+                     "concatenated slabs also copied from rank 0's HBM to its host inside the region" if multi else
                      "into pinned host memory (" + ("compact: u32 word + a count byte per read" if scope["form"] == "compact" else
                                                      "8-byte packed words" if scope["form"] == "packed64" else "16-byte tuples") + ")") +
                     "; database + index resident (uploaded once: one_off).  The pass with everything resident in HBM (r01-r03's `value`) "
