@@ -691,6 +691,14 @@ def main() -> int:
             legs["first_pass_device_ms"] = eng.stats()["ms_total"]
             assert n == n0
             del roff2
+    if multi and scope is not None:
+        legs["survey_scope"] = {
+            "ms_per_pass": scope["ms_per_step"], "host_ms_queue_upload": scope["host_ms_queue_upload"],
+            "host_ms_match_call": scope["host_ms_match_call"], "host_ms_tuples_out": scope["host_ms_tuples_out"],
+            "bytes_up": scope["bytes_up"], "bytes_down": scope["bytes_down"], "host_slabs_pinned": scope["host_slabs_pinned"],
+            "what": "rank 0's own figures (bytes per rank and step; host_ms_tuples_out = posting the gather + the copy of the rank's "
+                    "buffer into its slab of rank 0's pinned host buffer): see config.timed_region",
+        }
     legs["cold_pass_ms"] = cold_pass_ms
     legs["cold_pass_device_ms"] = cold_device_ms
 
