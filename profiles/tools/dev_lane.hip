@@ -21,4 +21,7 @@
 #ifndef DEV_WIDE
 #define DEV_WIDE false
 #endif
-template __global__ void k_match_t<DEV_RW, DEV_W, DEV_RX, DEV_WIDE> MUSC_LANE_ARGS;
+#ifndef DEV_SG
+#define DEV_SG 0  // 1: the geometry-specialised instance (SpecGeom<1>)
+#endif
+template __global__ void k_match_t<DEV_RW, DEV_W, DEV_RX, DEV_WIDE, DEV_SG> MUSC_LANE_ARGS;
