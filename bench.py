@@ -529,9 +529,22 @@ def main() -> int:
             path = [None]
             if rank == 0:
                 path[0] = "/dev/shm/musc_bench_%d_%s" % (os.getpid(), os.environ.get("MASTER_PORT", "0"))
-                with open(path[0], "wb") as f:
-                    f.truncate(sum(sizes))
+                try:
+                    with open(path[0], "wb") as f:
+                        os.posix_fallocate(f.fileno(), 0, sum(sizes))  # (reserved now: a mapping of a sparse file dies with SIGBUS when /dev/shm is full)
+                except OSError as e:
+                    log("no room for the shared host buffer (%r): every rank keeps its tuples in a pinned buffer of its own" % (e,))
+                    try:
+                        os.unlink(path[0])
+                    except OSError:
+                        pass
+                    path[0] = None
             dist.broadcast_object_list(path, src=0)
+            if path[0] is None:
+                src0 = gatherer.send[0][:gatherer.rows[rank]]
+                h_all[1] = torch.empty(src0.shape, dtype=src0.dtype, pin_memory=src0.is_cuda)
+                h_all[0] = (None, None, None, bool(src0.is_cuda))
+                return
             with open(path[0], "r+b") as f:
                 mm = mmap.mmap(f.fileno(), sum(sizes))
             arr = np.frombuffer(mm, dtype=np.uint8)
