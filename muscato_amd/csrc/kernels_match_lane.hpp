@@ -129,6 +129,13 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
   __shared__ uint32_t s_oix[NWAVE][WT];                   // overflow entries: item -> its entry in E
   __shared__ uint8_t s_own[NWAVE][WT];                    //                   item -> window * 64 + read slot
   __shared__ uint16_t s_nm[CONF_NM];
+  // Three windows, no X, records of up to eight words: the previous wave-tile's bucket numbers -- kept for ONE use, the
+  // MaxMatches block accounting in phase D one wave-tile later -- live in LDS, not in registers.  These instances sit at
+  // 256 VGPRs and the allocator spilled exactly those values; a scratch reload is a vector memory operation, so its wait
+  // (`vmcnt(0)`, per window, inside every wave-tile) drained the next wave-tile's bucket lines already in flight
+  // (r04; the same mechanism as in k_screen_t).  Only where 3 KB more LDS keep two workgroups on a CU.
+  constexpr bool BB_LDS = (W == 3 && XM == 0 && RW <= 8);
+  __shared__ uint32_t s_bbp[BB_LDS ? NWAVE : 1][BB_LDS ? W : 1][BB_LDS ? WT : 1];
 
   // the run's parameters: scalars for the whole kernel -- or, in an instance specialised for one geometry
   // (SpecGeom<SG>, kernels_match_lane_inst.hpp), compile-time constants: the mask tables become immediates, the
@@ -767,10 +774,10 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       if (block_mode) {
 #pragma unroll
         for (int k = 0; k < W; k++) {
-          const uint32_t cw = wc_prev[k] + wcnt_l[k * WT + lane];
+          const uint32_t cw = (BB_LDS ? 0u : wc_prev[k]) + wcnt_l[k * WT + lane];
           wcnt_l[k * WT + lane] = 0;
           if (!cw) continue;
-          const uint32_t h = block_hash32((uint32_t)k, bb_prev[k]);
+          const uint32_t h = block_hash32((uint32_t)k, BB_LDS ? s_bbp[BB_LDS ? wid : 0][BB_LDS ? k : 0][BB_LDS ? lane : 0] : bb_prev[k]);
           if (block_mode == 1) atomicAdd(&s_sketch[h >> (32 - MATCH_SKETCH_BITS)], cw);
           else atomicAdd(&block_table[h >> (32 - BLOCK_TABLE_BITS)], cw);
         }
@@ -1087,7 +1094,19 @@ __global__ __launch_bounds__(TILE, MATCHT_WAVES) void k_match_t(const uint32_t* 
       ulen_prev = ulen;
       total_prev = total_cur;
 #pragma unroll
-      for (int k = 0; k < W; k++) wc_prev[k] = wc[k], bb_prev[k] = bb_cur[k], bb_cur[k] = bb_nx[k], oc_prev[k] = oc[k], ovf_prev[k] = ovf[k];
+      for (int k = 0; k < W; k++) {
+        if constexpr (BB_LDS) {
+          // (and the lane's own accepted-pair counts go straight into the wave-tile's counter slots, which the overflow
+          // pass -- one iteration later -- adds to: nothing else touches them until then)
+          const uint32_t ln = opaque(threadIdx.x) & 63;
+          s_bbp[wid][k][ln] = bb_cur[k];
+          if (block_mode) s_dyn[(par * NWAVE + wid) * WT * W + k * WT + ln] += wc[k];
+        } else {
+          bb_prev[k] = bb_cur[k];
+          wc_prev[k] = wc[k];
+        }
+        bb_cur[k] = bb_nx[k], oc_prev[k] = oc[k], ovf_prev[k] = ovf[k];
+      }
       meta_cur = meta_nx;
       xw_cur = xw_nx;
       par ^= 1u;

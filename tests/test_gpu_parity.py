@@ -594,6 +594,19 @@ def test_maxmatches_overflow_is_detected(eng):
     c.MaxMatches = 12
     gpu_hits(eng, c, reads, targets, False)
     assert eng.stats()["n_overflow_blocks"] == 0 and len(eng.overflow_probes()) == 0
+    # three windows (the k_match_t instances that keep a wave-tile's bucket numbers and own counts in LDS, r04): windows 0
+    # and 1 match every target, window 2 (GTAA) only targets 0, 4, 8 -- each block counts its own acceptances
+    c = orc.Config(Windows=[0, 1, 2], WindowWidth=4, PMatch=0.5, MaxReadLength=50, MaxMatches=11)
+    got = gpu_hits(eng, c, reads, targets, False)
+    assert_same(got, as_arr(orc.match_direct(reads, targets, c, check_overflow=False)))
+    assert len(got) == 12 and eng.stats()["n_overflow_blocks"] >= 1
+    assert sorted(eng.overflow_probes().tolist()) == [[0, 0], [0, 1]]
+    c.MaxMatches = 2   # now window 2's block of three overflows as well
+    gpu_hits(eng, c, reads, targets, False)
+    assert sorted(eng.overflow_probes().tolist()) == [[0, 0], [0, 1], [0, 2]]
+    c.MaxMatches = 12
+    gpu_hits(eng, c, reads, targets, False)
+    assert eng.stats()["n_overflow_blocks"] == 0 and len(eng.overflow_probes()) == 0
 
 
 def test_no_overflow_reported_on_ordinary_cases(eng):
