@@ -711,6 +711,58 @@ def test_index_selection(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_three_window_block_accounting_agrees_across_paths(monkeypatch):
+    """MaxMatches accounting with three windows and many reads per (window, key) block: the fused kernel's
+    three-window instances keep a wave-tile's bucket numbers and own accepted-pair counts in LDS (r04), the
+    two-kernel path counts in k_confirm -- both must name the same overflowing probes, none when MaxMatches
+    is large, and return the oracle's tuples either way."""
+    from muscato_amd import Engine, sorted_hits
+    monkeypatch.delenv("MUSC_INDEX", raising=False)
+    monkeypatch.delenv("MUSC_MATCH", raising=False)
+    rng = random.Random(31)
+    motif = rand_seq(rng, 90, b"ACGT")
+    targets = [rand_seq(rng, 300, b"ACGT") for _ in range(80)]
+    for i in range(0, 40):   # the motif sits in forty targets: every read from it has forty placements
+        p = rng.randint(0, 200)
+        targets[i] = targets[i][:p] + motif + targets[i][p + 90:]
+    reads = set()
+    for _ in range(400):
+        if rng.random() < 0.7:
+            p = rng.randint(0, 30)
+            reads.add(mutate(rng, motif[p:p + 60], 0.01, b"ACGT"))
+        else:
+            t = rng.choice(targets[40:])
+            p = rng.randint(0, 240)
+            reads.add(mutate(rng, t[p:p + 60], 0.01, b"ACGT"))
+    reads = sorted(reads)
+    ocfg = orc.Config(Windows=[0, 10, 20], WindowWidth=10, PMatch=0.9, MinDinuc=2, MaxReadLength=60, MaxMatches=25, MMTol=2)
+    full = as_arr(orc.match_direct(reads, targets, ocfg, check_overflow=False))
+    seen = {}
+    with Engine(0) as eng:
+        eng.load_targets(targets)
+        eng.load_reads(reads)
+        for mode in ("auto", "classic"):
+            if mode == "classic":
+                monkeypatch.setenv("MUSC_INDEX", "classic")
+            eng.reload_env()
+            got = sorted_hits(eng.match(to_cfg(ocfg), apply_mmtol=False))
+            assert eng.stats()["index_kind"] == (1 if mode == "auto" else 0)
+            assert_same(got, full)
+            assert eng.stats()["n_overflow_blocks"] >= 1
+            seen[mode] = sorted(map(tuple, eng.overflow_probes().tolist()))
+        assert seen["auto"] == seen["classic"] and len(seen["auto"]) > 10
+        assert {k for _, k in seen["auto"]} == {0, 1, 2}   # every window has overflowing blocks
+        big = orc.Config(Windows=[0, 10, 20], WindowWidth=10, PMatch=0.9, MinDinuc=2, MaxReadLength=60, MaxMatches=1000000, MMTol=2)
+        for mode in ("classic", "auto"):
+            if mode == "auto":
+                monkeypatch.delenv("MUSC_INDEX")
+            eng.reload_env()
+            got = sorted_hits(eng.match(to_cfg(big), apply_mmtol=False))
+            assert_same(got, full)
+            assert eng.stats()["n_overflow_blocks"] == 0 and len(eng.overflow_probes()) == 0
+
+
+@pytest.mark.gpu
 def test_database_with_x_on_context_buckets(monkeypatch):
     """A database with X (N in the FASTA) stays on context buckets: a window that holds an X is not
     indexed, an entry whose context touches one is flagged and k_match_t<.., XM = 2> reads the target
